@@ -1,0 +1,120 @@
+/* ravvent_hip.h -- C-ABI of the MI355X-native Ravvent inference hot path (libravvent_hip.so).
+ *
+ * The reference has no FFI / plugin interface for this path: callers use the Python methods
+ * of `Basecaller` (a Keras Model subclass).  This header is therefore the boundary a ctypes
+ * binding of that class needs; each entry point names the reference method it stands behind
+ * (file:line into /root/reference).  INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types.  Every function returns 0 on
+ * success and a negative RV_E* code on failure; the message is available through
+ * rv_last_error().  Nothing throws across the boundary.  A handle is bound to ONE device and
+ * is NOT thread-safe (the reference is single-threaded and synchronous:
+ * ravvent_performance_evaluator.py:51-55); use one handle per GPU / per process.  All calls
+ * are synchronous: results are complete when the call returns, so a caller's wall-clock
+ * timers mean what they mean around the reference's methods.
+ *
+ * Host-buffer entry points copy inputs H2D / outputs D2H themselves.  The *_dev variants
+ * take device addresses valid on the handle's device (e.g. torch tensor data_ptr()) and move
+ * no data across PCIe.
+ */
+#ifndef RAVVENT_HIP_H
+#define RAVVENT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_ABI_VERSION 1
+
+enum { RV_OK = 0, RV_EINVAL = -1, RV_ENOMEM = -2, RV_EHIP = -3, RV_ESTATE = -4, RV_EUNSUPPORTED = -5 };
+enum { RV_MODE_RAW = 0, RV_MODE_EVENT = 1, RV_MODE_JOINT = 2 };      /* input_data_type, basecaller.py:180-185 */
+enum { RV_ATT_LUONG = 0, RV_ATT_BAHDANAU = 1 };                       /* basecaller.py:131-134 */
+
+/* Mirrors the arguments of Basecaller.__init__ (basecaller.py:158-206) that shape the
+ * inference path, plus the maximum shapes device memory is sized for. */
+typedef struct RvConfig {
+  int32_t enc_units;      /* LSTMCell units per direction (128)          basecaller.py:22 */
+  int32_t dec_units;      /* decoder LSTMCell units = attention depth    basecaller.py:86 */
+  int32_t enc_depth;      /* stacked BiLSTM layers per encoder           basecaller.py:31 */
+  int32_t dec_depth;      /* StackedRNNCells depth                       basecaller.py:85-91 */
+  int32_t mode;           /* RV_MODE_*                                                    */
+  int32_t attention;      /* RV_ATT_*                                                     */
+  int32_t vocab;          /* len(tokenizer.word_index) = 7               basecaller.py:189 */
+  int32_t start_token;    /* '$' = 2   basecaller.py:204 */
+  int32_t end_token;      /* '^' = 1   basecaller.py:205 */
+  int32_t pad_token;      /* ''  = 0   basecaller.py:206 */
+  float   padding_value;  /* INPUT_PADDING = 0.   data_loader.py:14 */
+  int32_t max_batch;      /* chunks per call (slab; evaluator uses 1024) */
+  int32_t max_raw_len;    /* T_r upper bound */
+  int32_t max_event_len;  /* T_e upper bound */
+  int32_t max_output_len; /* L upper bound (decode runs at most L-1 steps) */
+  int32_t max_beam;       /* beam width upper bound (<= 8) */
+  int32_t device;         /* HIP device ordinal */
+} RvConfig;
+
+typedef struct RvContext* rv_handle;
+
+int rv_abi_version(void);
+
+/* Basecaller.__init__: allocates every device buffer, streams and graphs for the max shapes. */
+int rv_create(const RvConfig* cfg, rv_handle* out);
+void rv_destroy(rv_handle h);
+
+/* Message of the last failing call on this handle (h == NULL: last rv_create failure). */
+const char* rv_last_error(rv_handle h);
+
+/* Number of fp32 values rv_load_weights expects for this handle's config. */
+size_t rv_weight_count(rv_handle h);
+
+/* Basecaller.load_weights (ravvent_performance_evaluator.py:107): flat little-endian fp32
+ * blob, order documented in ravvent-basecaller_amd/weights.py. Host pointer. */
+int rv_load_weights(rv_handle h, const float* blob, size_t n_floats);
+
+/* Basecaller.beam_search_prediction (basecaller.py:296-315).
+ *   raw   [B,T_r,1] f32 (NULL in event mode), event [B,T_e,5] f32 (NULL in raw mode),
+ *   W beam width, L = max_output_len (decode runs S <= L-1 steps, S returned in *S_out).
+ *   tokens [B, L-1] i32 and scores [B, L-1] f32, row stride L-1; columns [0,S) are
+ *   predicted_ids[:,:,0] and beam_search_decoder_output.scores[:,:,0]; columns >= S are
+ *   pad_token / 0. */
+int rv_beam_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r,
+                   int32_t T_e, int32_t W, int32_t L, int32_t* tokens, float* scores, int32_t* S_out);
+int rv_beam_search_dev(rv_handle h, const float* d_raw, const float* d_event, int32_t B, int32_t T_r,
+                       int32_t T_e, int32_t W, int32_t L, int32_t* d_tokens, float* d_scores,
+                       int32_t* S_out);
+
+/* Basecaller.greedy_search_prediction (basecaller.py:317-330): tokens = sample_id [B, L-1],
+ * logits = rnn_output [B, L-1, vocab]; columns >= S are pad_token / 0. */
+int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r,
+                     int32_t T_e, int32_t L, int32_t* tokens, float* logits, int32_t* S_out);
+int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, int32_t B, int32_t T_r,
+                         int32_t T_e, int32_t L, int32_t* d_tokens, float* d_logits, int32_t* S_out);
+
+/* Options: "debug_taps" (0/1: keep per-step logits/alignments for rv_get_tensor),
+ *          "use_graph"  (0/1: replay the decode loop from a captured hipGraph),
+ *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around
+ *                       the graph as a whole; 2: no graph, events around every kernel). */
+int rv_set_option(rv_handle h, const char* key, int32_t value);
+
+/* Debug taps of the LAST call, copied to host as fp32 (bool/int tensors are converted):
+ *   "enc_output" [B,T_m,2u]   _encode_input's output              basecaller.py:405
+ *   "mask"       [B,T_m]      input_mask (1.0 / 0.0)              basecaller.py:406
+ *   "keys"       [B,T_m,d]    attention keys after setup_memory   basecaller.py:303
+ *   "step_logits"     [S,B,W,V]   (needs debug_taps)
+ *   "step_alignments" [S,B,W,T_m] (needs debug_taps)
+ *   "step_ids" / "parent_ids" / "step_scores" [S,B,W]
+ * n_written receives the element count; fails with RV_EINVAL if dst is too small. */
+int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, size_t* n_written);
+
+/* Profile read-out ("profile" option): accumulated device time and launch count of the named
+ * kernel since the last rv_reset_profile; rv_profile_names fills a ';'-separated list. */
+int rv_get_profile(rv_handle h, const char* kernel, double* total_ms, int64_t* launches);
+int rv_profile_names(rv_handle h, char* dst, size_t dst_bytes);
+int rv_reset_profile(rv_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAVVENT_HIP_H */

@@ -1,0 +1,240 @@
+"""`Basecaller`: the reference's class API (/root/reference/basecaller.py:156-416) in front of
+the HIP path.  Same constructor signature, same method names, argument meaning and return
+shapes as the two evaluators rely on (ravvent_performance_evaluator.py:91-107,51-67;
+SURVEY.md 8b); every number is produced by libravvent_hip.so on the GPU.
+
+Returned tensors are ``torch.Tensor`` (they support ``.numpy()`` like the TF tensors the
+callers expect).  Inputs may be numpy arrays or torch tensors, host or device; host inputs go
+through the host-buffer C entry points (PCIe copies included), CUDA/HIP tensors through the
+``*_dev`` entry points with no host round trip.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi, weights as _weights
+from .config import RvConfig, RAW_FEATURES, EVENT_FEATURES
+from .data_loader import tokens_to_strings
+
+
+def _as_int(x) -> int:
+    """max_output_len arrives as tf.shape(target)[1] in the reference (a 0-d tensor)."""
+    if isinstance(x, torch.Tensor):
+        return int(x.item())
+    return int(np.asarray(x).reshape(()))
+
+
+class Basecaller:
+    def __init__(self, enc_units: int, dec_units: int, batch_sz: int, tokenizer, input_data_type: str,
+                 input_padding_value, encoder_depth: int = 2, decoder_depth: int = 1,
+                 rnn_type: str = "bilstm", teacher_forcing=True, attention_type: str = "luong",
+                 beam_width: int = 5, *, device: int | None = None, max_batch: int = 1024,
+                 max_raw_len: int = 300, max_event_len: int = 45, max_output_len: int = 64,
+                 honor_attention_type: bool = False):
+        """Positional / keyword arguments are those of the reference constructor
+        (basecaller.py:158).  Keyword-only extras size device memory.
+
+        The reference hard-codes Luong attention when it builds its Decoder
+        (basecaller.py:194) and only stores ``attention_type`` (:201); that behaviour is kept
+        unless ``honor_attention_type=True`` selects the Bahdanau mechanism that
+        ``Decoder(attention_type='bahdanau')`` builds (basecaller.py:131-132)."""
+        if rnn_type != "bilstm":
+            raise NotImplementedError(
+                f"rnn_type={rnn_type!r}: only the BiLSTM encoder / LSTM decoder of the north-star path is built")
+        if input_data_type not in ("raw", "event", "joint"):
+            raise ValueError(f"input_data_type {input_data_type!r}")
+        self.batch_sz = batch_sz
+        self.rnn_type = rnn_type
+        self.tokenizer = tokenizer
+        self.teacher_forcing = teacher_forcing
+        self.input_data_type = input_data_type
+        self.input_padding_value = input_padding_value
+        self.attention_type = attention_type
+        self.beam_width = beam_width
+        self.max_input_len = {"raw": 200, "event": 30, "joint": 230}[input_data_type]   # basecaller.py:180-185
+        self.output_start_token = np.int32(tokenizer.word_index["$"])
+        self.output_end_token = np.int32(tokenizer.word_index["^"])
+        self.output_padding_token = np.int32(tokenizer.word_index[""])
+
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.cfg = RvConfig(
+            enc_units=enc_units, dec_units=dec_units, enc_depth=encoder_depth, dec_depth=decoder_depth,
+            mode=input_data_type,
+            attention=attention_type if honor_attention_type else "luong",
+            vocab=len(tokenizer.word_index),
+            start_token=int(self.output_start_token), end_token=int(self.output_end_token),
+            pad_token=int(self.output_padding_token), padding_value=float(input_padding_value),
+            max_batch=max_batch, max_raw_len=max_raw_len, max_event_len=max_event_len,
+            max_output_len=max_output_len, max_beam=8, device=device)
+        self.device = torch.device("cuda", device)
+        self._lib = _capi.load_library()
+        self._h = ctypes.c_void_p()
+        ccfg = self.cfg.to_c()
+        rc = self._lib.rv_create(ctypes.byref(ccfg), ctypes.byref(self._h))
+        _capi.check(self._lib, None, rc, "rv_create")
+        self.optimizer = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rv_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compile(self, optimizer=None, **kwargs):
+        """Keras ``compile`` (ravvent_performance_evaluator.py:104): inference needs no
+        optimizer; accepted and ignored."""
+        self.optimizer = optimizer
+
+    def _check(self, rc, what):
+        _capi.check(self._lib, self._h, rc, what)
+
+    # ------------------------------------------------------------------ weights
+    def set_weights_flat(self, flat: dict):
+        blob = _weights.pack(self.cfg, flat)
+        self._check(self._lib.rv_load_weights(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size),
+                    "rv_load_weights")
+
+    def load_weights(self, path):
+        """ravvent_performance_evaluator.py:107.  Reads this build's ``.npz`` weight file
+        (weights.py); TF-format checkpoints need TensorFlow and are out of scope."""
+        self.set_weights_flat(_weights.load(str(path), self.cfg))
+        return self
+
+    def init_random_weights(self, seed: int = 22, scheme: str = "keras", gain: float = 1.0):
+        flat = _weights.init_weights(self.cfg, seed=seed, scheme=scheme, gain=gain)
+        self.set_weights_flat(flat)
+        return flat
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.rv_set_option(self._h, key.encode(), int(value)), f"rv_set_option({key})")
+
+    # ------------------------------------------------------------------ input plumbing
+    def _split_inputs(self, input_data):
+        if self.input_data_type == "joint":
+            raw, ev = input_data
+        elif self.input_data_type == "raw":
+            raw, ev = input_data, None
+        else:
+            raw, ev = None, input_data
+        return raw, ev
+
+    def _prep(self, x, feat):
+        """-> (keepalive, pointer, B, T, on_device)"""
+        if x is None:
+            return None, None, None, 0, None
+        if isinstance(x, torch.Tensor):
+            if x.dim() != 3 or x.shape[-1] != feat:
+                raise ValueError(f"expected [B,T,{feat}], got {tuple(x.shape)}")
+            if x.is_cuda:
+                if x.device != self.device:
+                    raise ValueError(f"input on {x.device}, basecaller on {self.device}")
+                t = x.detach().to(torch.float32).contiguous()
+                return t, ctypes.c_void_p(t.data_ptr()), t.shape[0], t.shape[1], True
+            x = x.detach().cpu().numpy()
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+        if a.ndim != 3 or a.shape[-1] != feat:
+            raise ValueError(f"expected [B,T,{feat}], got {a.shape}")
+        return a, a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], False
+
+    def _gather_inputs(self, input_data):
+        raw, ev = self._split_inputs(input_data)
+        kr, pr, Br, Tr, dr = self._prep(raw, RAW_FEATURES)
+        ke, pe, Be, Te, de = self._prep(ev, EVENT_FEATURES)
+        if kr is not None and ke is not None:
+            if Br != Be:
+                raise ValueError(f"raw batch {Br} != event batch {Be}")
+            if dr != de:   # mixed residency: bring both to the host path
+                if dr:
+                    return self._gather_inputs((kr.cpu(), ke))
+                return self._gather_inputs((kr, ke.cpu()))
+        B = Br if kr is not None else Be
+        on_dev = dr if kr is not None else de
+        return (kr, ke), pr, pe, B, Tr, Te, on_dev
+
+    # ------------------------------------------------------------------ the hot path
+    def beam_search_prediction(self, input_data, beam_width, max_output_len):
+        """basecaller.py:296-315 -> (predicted_ids[:,:,0] [B,S] int32, scores[:,:,0] [B,S] f32)."""
+        keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
+        L, W = _as_int(max_output_len), int(beam_width)
+        steps = max(L - 1, 0)
+        S = ctypes.c_int32(0)
+        if on_dev:
+            torch.cuda.current_stream(self.device).synchronize()   # inputs ready before the library's stream reads them
+            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
+            scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
+            rc = self._lib.rv_beam_search_dev(self._h, pr, pe, B, Tr, Te, W, L,
+                                              ctypes.c_void_p(tokens.data_ptr()), ctypes.c_void_p(scores.data_ptr()),
+                                              ctypes.byref(S))
+        else:
+            tk = np.empty((B, steps), np.int32)
+            sc = np.empty((B, steps), np.float32)
+            rc = self._lib.rv_beam_search(self._h, pr, pe, B, Tr, Te, W, L,
+                                          tk.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.byref(S))
+            tokens, scores = torch.from_numpy(tk), torch.from_numpy(sc)
+        self._check(rc, "rv_beam_search")
+        self.last_steps = S.value
+        return tokens[:, :S.value], scores[:, :S.value]
+
+    def greedy_search_prediction(self, input_data, max_output_len):
+        """basecaller.py:317-330 -> (sample_id [B,S] int32, rnn_output logits [B,S,V] f32)."""
+        keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
+        L, V = _as_int(max_output_len), self.cfg.vocab
+        steps = max(L - 1, 0)
+        S = ctypes.c_int32(0)
+        if on_dev:
+            torch.cuda.current_stream(self.device).synchronize()
+            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
+            logits = torch.empty((B, steps, V), dtype=torch.float32, device=self.device)
+            rc = self._lib.rv_greedy_search_dev(self._h, pr, pe, B, Tr, Te, L,
+                                                ctypes.c_void_p(tokens.data_ptr()), ctypes.c_void_p(logits.data_ptr()),
+                                                ctypes.byref(S))
+        else:
+            tk = np.empty((B, steps), np.int32)
+            lg = np.empty((B, steps, V), np.float32)
+            rc = self._lib.rv_greedy_search(self._h, pr, pe, B, Tr, Te, L,
+                                            tk.ctypes.data_as(ctypes.c_void_p), lg.ctypes.data_as(ctypes.c_void_p),
+                                            ctypes.byref(S))
+            tokens, logits = torch.from_numpy(tk), torch.from_numpy(lg)
+        self._check(rc, "rv_greedy_search")
+        self.last_steps = S.value
+        return tokens[:, :S.value], logits[:, :S.value]
+
+    def tokens_to_nuc_sequences(self, result_tokens):
+        """basecaller.py:289-294"""
+        if isinstance(result_tokens, torch.Tensor):
+            result_tokens = result_tokens.detach().cpu().numpy()
+        return tokens_to_strings(result_tokens)
+
+    # ------------------------------------------------------------------ debug taps / profile
+    def get_tensor(self, name: str) -> np.ndarray:
+        n = ctypes.c_size_t(0)
+        self._lib.rv_get_tensor(self._h, name.encode(), None, 0, ctypes.byref(n))
+        out = np.empty(n.value, np.float32)
+        self._check(self._lib.rv_get_tensor(self._h, name.encode(), out.ctypes.data_as(ctypes.c_void_p),
+                                            out.size, ctypes.byref(n)), f"rv_get_tensor({name})")
+        return out
+
+    def profile(self) -> dict:
+        buf = ctypes.create_string_buffer(4096)
+        self._check(self._lib.rv_profile_names(self._h, buf, len(buf)), "rv_profile_names")
+        out = {}
+        for name in filter(None, buf.value.decode().split(";")):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            self._check(self._lib.rv_get_profile(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(n)),
+                        "rv_get_profile")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def reset_profile(self):
+        self._check(self._lib.rv_reset_profile(self._h), "rv_reset_profile")

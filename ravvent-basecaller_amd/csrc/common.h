@@ -1,0 +1,99 @@
+// Shared declarations of the gfx950 kernels behind libravvent_hip.so.
+// Units are fixed at u = d = 128 (every reference script uses 128:
+// /root/reference/ravvent_performance_evaluator.py:92-93, ravvent.py:14-15); the recurrence
+// kernel's register tiling is built around that number.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RV_U 128          // LSTM units per direction / decoder units
+#define RV_G 512          // 4 gates x RV_U
+#define RV_E 256          // encoder output width 2u
+#define RV_MAX_BEAM 8
+#define RV_MAX_VOCAB 8
+
+// ---------------------------------------------------------------- K1: BiLSTM recurrence
+struct RecArgs {
+  const float* x;        // F>0: chunk input [B,T,F];  F==0: pre-projected xw [B,T,2,512] (bias folded)
+  const float* W[2];     // F>0: input kernel [F,512] per direction
+  const float* bias[2];  // F>0: [512] per direction
+  const float* U[2];     // recurrent kernel [128,512] per direction
+  const float* h0[2];    // initial states [B,128] or nullptr (zeros)
+  const float* c0[2];
+  float* hT[2];          // final states [B,128]
+  float* cT[2];
+  float* out;            // [B,out_T,256]; direction d writes columns [128d,128d+128) at time out_t0+t
+  int out_T, out_t0;
+  int B, T;
+};
+// F in {0,1,5}; rows_per_block in {1,2,4,8}
+void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s);
+
+// ---------------------------------------------------------------- K0/K2: fp32 MFMA GEMM
+struct GemmArgs {
+  const float* A; int lda;     // [M,K]
+  const float* Bm; int ldb;    // [K,N]
+  float* C; int ldc;           // [M,N]
+  int M, N, K;                 // K % 16 == 0, N % 64 == 0
+  const float* bias;           // [N] or nullptr
+  const uint8_t* row_mask;     // [M] or nullptr: masked-off rows are written as 0
+  const int* gather_idx;       // [M] or nullptr: adds gather_tab[gather_idx[m]*ld_tab + n]
+  const float* gather_tab; int ld_tab;
+  const int* skip_flag; int skip_when;   // if skip_flag && *skip_flag >= skip_when: kernel exits
+};
+void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s);
+
+// ---------------------------------------------------------------- small encoder-side kernels
+void launch_input_mask(const float* raw, const float* ev, int B, int T_r, int T_e, float pad,
+                       uint8_t* mask /*[B,T_r+T_e]*/, hipStream_t s);
+
+// ---------------------------------------------------------------- decoder
+struct DecState {
+  // per-call shapes
+  int B, W, Tm, V, L;
+  int greedy, attention;
+  int start_token, end_token, pad_token;
+  // memory
+  const float* keys;      // [B,Tm,128]
+  const float* values;    // [B,Tm,256]  (= enc_output; masked positions never contribute)
+  const uint8_t* mask;    // [B,Tm]
+  // recurrent state, N = B*W rows
+  float* xh;              // [N,256] = [attention | h]  (cell GEMM A operand)
+  float* z;               // [N,512] gate pre-activations
+  float* c;               // [N,128]
+  float* c_new;           // [N,128]
+  float* h_new;           // [N,128]
+  int* tok;               // [N]
+  float* log_probs;       // [N]
+  uint8_t* finished;      // [N]
+  int* lengths;           // [N]
+  // weights
+  const float* W_att;     // [384,128]
+  const float* W_fc;      // [128,V]
+  const float* b_fc;      // [V]
+  const float* W_q;       // [128,128]
+  const float* v_att;     // [128]
+  // per-step records, time-major
+  int* step_ids;          // [L-1,B,W]
+  int* parent_ids;        // [L-1,B,W]
+  float* step_scores;     // [L-1,B,W]
+  float* step_logits;     // [L-1,B,W,V]   (greedy or debug) or nullptr
+  float* step_align;      // [L-1,B,W,Tm]  (debug) or nullptr
+  int* nfin;              // [L] chunks-finished counter per step
+  int* S_dev;             // [1]
+};
+void launch_dec_init(const DecState& d, hipStream_t s);
+void launch_dec_gates(const DecState& d, int step, hipStream_t s);
+void launch_dec_attend(const DecState& d, int step, hipStream_t s);
+void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
+
+// ---------------------------------------------------------------- device math helpers
+#ifdef __HIPCC__
+__device__ __forceinline__ float rv_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float rv_tanh(float x) {
+  // tanh(x) = 2*sigmoid(2x) - 1 ; absolute error ~1e-7, saturates cleanly
+  return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f);
+}
+#endif

@@ -1,0 +1,543 @@
+// libravvent_hip.so -- host side of the C-ABI declared in include/ravvent_hip.h.
+// Owns device memory, the stream, the decode hipGraph cache and the launch sequence that
+// stands behind Basecaller.beam_search_prediction / greedy_search_prediction
+// (/root/reference/basecaller.py:296-330).  No CPU compute path exists in this library.
+#include "../../include/ravvent_hip.h"
+#include "common.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct LstmW { const float *W, *U, *b; };
+
+struct ProfEntry { double ms = 0; int64_t n = 0; };
+
+struct GraphKey {
+  int B, W, Tm, L, greedy, taps;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(B, W, Tm, L, greedy, taps) < std::tie(o.B, o.W, o.Tm, o.L, o.greedy, o.taps);
+  }
+};
+
+}  // namespace
+
+struct RvContext {
+  RvConfig cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<void*> allocs;
+
+  // weights
+  float* d_w = nullptr;
+  size_t n_w = 0;
+  bool loaded = false;
+  std::vector<std::vector<LstmW>> enc[2];   // [enc][layer][dir]
+  LstmW dec{};
+  const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
+
+  // encoder buffers
+  float *d_raw = nullptr, *d_ev = nullptr;
+  uint8_t* mask = nullptr;
+  float* act[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [enc][pingpong]
+  float* xw = nullptr;
+  float* st[2][4] = {};     // [set][h_f, c_f, h_b, c_b]
+  float *enc_out = nullptr, *keys = nullptr;
+  // decoder buffers
+  DecState dec_st{};
+  float* step_align = nullptr; size_t step_align_cap = 0;
+  int32_t* out_tokens = nullptr;
+  float* out2 = nullptr;
+
+  int opt_taps = 0, opt_graph = 1, opt_profile = 0;
+  std::map<std::string, ProfEntry> prof;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+
+  // last call
+  int lB = 0, lW = 0, lTm = 0, lL = 0, lS = 0, lgreedy = 0, ltaps = 0;
+};
+
+namespace {
+
+int fail(RvContext* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(h, RV_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+int dalloc(RvContext* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) return fail(h, RV_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return RV_OK;
+}
+
+size_t weight_count(const RvConfig& c) {
+  const size_t u = c.enc_units, d = c.dec_units, V = c.vocab;
+  size_t n = 0;
+  for (int e = 0; e < 2; ++e)
+    for (int l = 0; l < c.enc_depth; ++l) {
+      const size_t F = l > 0 ? 2 * u : (e == 0 ? 1 : 5);
+      n += 2 * (F * 4 * u + u * 4 * u + 4 * u);
+    }
+  for (int k = 0; k < c.dec_depth; ++k) {
+    const size_t fin = k == 0 ? V + d : d;
+    n += fin * 4 * d + d * 4 * d + 4 * d;
+  }
+  n += 2 * u * d + d * d + d + (d + 2 * u) * d + d * V + V;
+  return n;
+}
+
+void bind_weights(RvContext* h) {
+  const RvConfig& c = h->cfg;
+  const size_t u = c.enc_units, d = c.dec_units, V = c.vocab;
+  const float* p = h->d_w;
+  for (int e = 0; e < 2; ++e) {
+    h->enc[e].assign(c.enc_depth, std::vector<LstmW>(2));
+    for (int l = 0; l < c.enc_depth; ++l) {
+      const size_t F = l > 0 ? 2 * u : (e == 0 ? 1 : 5);
+      for (int dr = 0; dr < 2; ++dr) {
+        LstmW& w = h->enc[e][l][dr];
+        w.W = p; p += F * 4 * u;
+        w.U = p; p += u * 4 * u;
+        w.b = p; p += 4 * u;
+      }
+    }
+  }
+  h->dec.W = p; p += (V + d) * 4 * d;
+  h->dec.U = p; p += d * 4 * d;
+  h->dec.b = p; p += 4 * d;
+  h->W_mem = p; p += 2 * u * d;
+  h->W_q = p; p += d * d;
+  h->v_att = p; p += d;
+  h->W_att = p; p += (d + 2 * u) * d;
+  h->W_fc = p; p += d * V;
+  h->b_fc = p; p += V;
+}
+
+// ---- profiling: bracket a launch with events on the launch stream
+struct Scope {
+  RvContext* h; const char* name; hipEvent_t a = nullptr, b = nullptr; bool on;
+  Scope(RvContext* h_, const char* n) : h(h_), name(n), on(h_->opt_profile != 0) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+      else hipEventCreate(&e);
+      return e;
+    };
+    a = get(); b = get();
+    hipEventRecord(a, h->stream);
+  }
+  ~Scope() {
+    if (!on) return;
+    hipEventRecord(b, h->stream);
+    h->pending.push_back({name, a, b});
+  }
+};
+
+void drain_profile(RvContext* h) {
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ProfEntry& e = h->prof[p.name];
+      e.ms += ms; e.n += 1;
+    }
+    h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+int pick_rows_per_block(int B) {
+  // one direction of BT chunks per workgroup, 2 directions: aim at <= 256 workgroups (1 per CU)
+  int bt = (2 * B + 255) / 256;
+  int r = 1;
+  while (r < bt && r < 8) r <<= 1;
+  return r;
+}
+
+// Encoder.call for one encoder (basecaller.py:48-59) writing into enc_out at time offset t_off.
+void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off) {
+  const int depth = h->cfg.enc_depth;
+  const int bt = pick_rows_per_block(B);
+  hipStream_t s = h->stream;
+  for (int l = 0; l < depth; ++l) {
+    const bool last = l == depth - 1;
+    float* out = last ? h->enc_out : h->act[e][l & 1];
+    RecArgs a{};
+    a.B = B; a.T = T;
+    a.out = out; a.out_T = last ? Tm : T; a.out_t0 = last ? t_off : 0;
+    const int rd = (l & 1) ^ 1, wr = l & 1;     // state sets: layer l reads set rd, writes set wr
+    for (int dr = 0; dr < 2; ++dr) {
+      const LstmW& w = h->enc[e][l][dr];
+      a.U[dr] = w.U;
+      a.h0[dr] = l > 0 ? h->st[rd][2 * dr] : nullptr;
+      a.c0[dr] = l > 0 ? h->st[rd][2 * dr + 1] : nullptr;
+      a.hT[dr] = h->st[wr][2 * dr];
+      a.cT[dr] = h->st[wr][2 * dr + 1];
+    }
+    if (l == 0) {
+      a.x = x;
+      for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
+      Scope sc(h, e == 0 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0");
+      launch_lstm_rec(a, F, bt, s);
+    } else {
+      const float* in = h->act[e][(l - 1) & 1];
+      for (int dr = 0; dr < 2; ++dr) {
+        GemmArgs g{};
+        g.A = in; g.lda = RV_E; g.Bm = h->enc[e][l][dr].W; g.ldb = RV_G;
+        g.C = h->xw + dr * RV_G; g.ldc = 2 * RV_G;
+        g.M = B * T; g.N = RV_G; g.K = RV_E; g.bias = h->enc[e][l][dr].b;
+        Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event");
+        launch_gemm_f32(g, false, s);
+      }
+      a.x = h->xw;
+      Scope sc(h, e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p");
+      launch_lstm_rec(a, 0, bt, s);
+    }
+  }
+}
+
+void launch_decode_steps(RvContext* h, const DecState& d, const GemmArgs& cell, hipStream_t s, bool profiled) {
+  for (int step = 0; step < d.L - 1; ++step) {
+    GemmArgs g = cell;
+    g.skip_flag = step > 0 ? d.nfin + (step - 1) : nullptr;
+    g.skip_when = d.B;
+    if (profiled) {
+      { Scope sc(h, "gemm_dec_cell"); launch_gemm_f32(g, true, s); }
+      { Scope sc(h, "dec_gates"); launch_dec_gates(d, step, s); }
+      { Scope sc(h, "dec_attend"); launch_dec_attend(d, step, s); }
+    } else {
+      launch_gemm_f32(g, true, s);
+      launch_dec_gates(d, step, s);
+      launch_dec_attend(d, step, s);
+    }
+  }
+}
+
+int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W,
+        int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, int32_t* S_out) {
+  if (!h) return RV_EINVAL;
+  const RvConfig& c = h->cfg;
+  if (!h->loaded) return fail(h, RV_ESTATE, "no weights loaded (call rv_load_weights first)");
+  const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
+  if (!use_raw) T_r = 0;
+  if (!use_ev) T_e = 0;
+  if (B < 0 || B > c.max_batch) return fail(h, RV_EINVAL, "B=%d outside [0,%d]", B, c.max_batch);
+  if (use_raw && (T_r < 1 || T_r > c.max_raw_len)) return fail(h, RV_EINVAL, "T_r=%d outside [1,%d]", T_r, c.max_raw_len);
+  if (use_ev && (T_e < 1 || T_e > c.max_event_len)) return fail(h, RV_EINVAL, "T_e=%d outside [1,%d]", T_e, c.max_event_len);
+  if (W < 1 || W > c.max_beam || W > RV_MAX_BEAM) return fail(h, RV_EINVAL, "beam width %d outside [1,%d]", W, std::min(c.max_beam, RV_MAX_BEAM));
+  if (L < 1 || L > c.max_output_len) return fail(h, RV_EINVAL, "max_output_len=%d outside [1,%d]", L, c.max_output_len);
+  if ((use_raw && !raw) || (use_ev && !ev)) return fail(h, RV_EINVAL, "missing input pointer for this mode");
+  if (!S_out || (B > 0 && L > 1 && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
+  HIPCHK(h, hipSetDevice(c.device));
+  h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps;
+  *S_out = 0;
+  if (B == 0 || L <= 1) return RV_OK;
+
+  hipStream_t s = h->stream;
+  const int Tm = T_r + T_e, V = c.vocab, steps = L - 1;
+  const float *xr = raw, *xe = ev;
+  if (!dev_in) {
+    if (use_raw) { HIPCHK(h, hipMemcpyAsync(h->d_raw, raw, sizeof(float) * B * T_r, hipMemcpyHostToDevice, s)); xr = h->d_raw; }
+    if (use_ev) { HIPCHK(h, hipMemcpyAsync(h->d_ev, ev, sizeof(float) * B * T_e * 5, hipMemcpyHostToDevice, s)); xe = h->d_ev; }
+  }
+
+  // ---- _encode_input (basecaller.py:395-416)
+  { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
+  if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0);
+  if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r);
+
+  // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem
+  {
+    GemmArgs g{};
+    g.A = h->enc_out; g.lda = RV_E; g.Bm = h->W_mem; g.ldb = RV_U; g.C = h->keys; g.ldc = RV_U;
+    g.M = B * Tm; g.N = RV_U; g.K = RV_E; g.row_mask = h->mask;
+    Scope sc(h, "gemm_keys");
+    launch_gemm_f32(g, false, s);
+  }
+
+  // ---- decode loop
+  DecState d = h->dec_st;
+  d.B = B; d.W = greedy ? 1 : W; d.Tm = Tm; d.V = V; d.L = L;
+  d.greedy = greedy; d.attention = c.attention;
+  d.start_token = c.start_token; d.end_token = c.end_token; d.pad_token = c.pad_token;
+  d.keys = h->keys; d.values = h->enc_out; d.mask = h->mask;
+  d.W_att = h->W_att; d.W_fc = h->W_fc; d.b_fc = h->b_fc; d.W_q = h->W_q; d.v_att = h->v_att;
+  const int N = B * d.W;
+  if (h->opt_taps) {
+    const size_t need = (size_t)steps * N * Tm;
+    if (need > h->step_align_cap) {
+      if (h->step_align) hipFree(h->step_align);
+      h->step_align = nullptr; h->step_align_cap = 0;
+      for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // captured args hold the old pointer
+      h->graphs.clear();
+      HIPCHK(h, hipMalloc((void**)&h->step_align, need * sizeof(float)));
+      h->step_align_cap = need;
+    }
+    d.step_align = h->step_align;
+  } else {
+    d.step_align = nullptr;
+    if (!greedy) d.step_logits = nullptr;
+  }
+  HIPCHK(h, hipMemsetAsync(d.xh, 0, sizeof(float) * N * RV_E, s));
+  HIPCHK(h, hipMemsetAsync(d.c, 0, sizeof(float) * N * RV_U, s));
+  launch_dec_init(d, s);
+
+  GemmArgs cell{};
+  cell.A = d.xh; cell.lda = RV_E;
+  cell.Bm = h->dec.W + (size_t)V * RV_G; cell.ldb = RV_G;     // rows V..V+127 of W_dec, then U_dec: contiguous [256,512]
+  cell.C = d.z; cell.ldc = RV_G; cell.M = N; cell.N = RV_G; cell.K = RV_E;
+  cell.bias = h->dec.b; cell.gather_idx = d.tok; cell.gather_tab = h->dec.W; cell.ld_tab = RV_G;
+
+  if (h->opt_graph && h->opt_profile != 2) {
+    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      launch_decode_steps(h, d, cell, s, false);
+      HIPCHK(h, hipStreamEndCapture(s, &graph));
+      hipGraphExec_t exec = nullptr;
+      HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      it = h->graphs.emplace(key, exec).first;
+    }
+    Scope sc(h, "decode_graph");
+    HIPCHK(h, hipGraphLaunch(it->second, s));
+  } else {
+    launch_decode_steps(h, d, cell, s, h->opt_profile == 2);
+  }
+
+  int32_t* tk = dev_out ? tokens : h->out_tokens;
+  float* o2 = dev_out ? out2 : h->out2;
+  { Scope sc(h, "dec_finalize"); launch_dec_finalize(d, tk, o2, s); }
+  int S = 0;
+  HIPCHK(h, hipMemcpyAsync(&S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (!dev_out) {
+    HIPCHK(h, hipMemcpyAsync(tokens, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  drain_profile(h);
+  *S_out = S;
+  h->lS = S;
+  h->lW = d.W;
+  return RV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rv_abi_version(void) { return RV_ABI_VERSION; }
+
+const char* rv_last_error(rv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rv_create(const RvConfig* cfg, rv_handle* out) {
+  if (!cfg || !out) return fail(nullptr, RV_EINVAL, "null argument");
+  *out = nullptr;
+  const RvConfig& c = *cfg;
+  if (c.enc_units != RV_U || c.dec_units != RV_U)
+    return fail(nullptr, RV_EUNSUPPORTED, "this build is specialised for enc_units = dec_units = 128 (got %d, %d)", c.enc_units, c.dec_units);
+  if (c.dec_depth != 1)
+    return fail(nullptr, RV_EUNSUPPORTED, "decoder_depth %d not supported yet (1 only)", c.dec_depth);
+  if (c.enc_depth < 1 || c.enc_depth > 8) return fail(nullptr, RV_EINVAL, "encoder_depth %d outside [1,8]", c.enc_depth);
+  if (c.vocab < 2 || c.vocab > RV_MAX_VOCAB) return fail(nullptr, RV_EINVAL, "vocab %d outside [2,%d]", c.vocab, RV_MAX_VOCAB);
+  if (c.mode < 0 || c.mode > 2 || c.attention < 0 || c.attention > 1) return fail(nullptr, RV_EINVAL, "bad mode/attention");
+  if (c.max_beam < 1 || c.max_beam > RV_MAX_BEAM) return fail(nullptr, RV_EINVAL, "max_beam %d outside [1,%d]", c.max_beam, RV_MAX_BEAM);
+  if (c.max_batch < 1 || c.max_raw_len < 1 || c.max_event_len < 1 || c.max_output_len < 1)
+    return fail(nullptr, RV_EINVAL, "maximum shapes must be positive");
+  for (int t : {c.start_token, c.end_token, c.pad_token})
+    if (t < 0 || t >= c.vocab) return fail(nullptr, RV_EINVAL, "token id %d outside vocab", t);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, RV_EHIP, "no HIP device visible: libravvent_hip has no CPU path");
+  if (c.device < 0 || c.device >= ndev) return fail(nullptr, RV_EINVAL, "device %d outside [0,%d)", c.device, ndev);
+
+  RvContext* h = new RvContext();
+  h->cfg = c;
+  auto bail = [&](int code) { g_create_error = h->err; rv_destroy(h); return code; };
+#define TRY(x) do { int r_ = (x); if (r_ != RV_OK) return bail(r_); } while (0)
+#define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(h, RV_EHIP, "%s: %s", #x, hipGetErrorString(e_)); return bail(RV_EHIP); } } while (0)
+  HIPTRY(hipSetDevice(c.device));
+  HIPTRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
+  const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
+  const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
+  h->n_w = weight_count(c);
+  TRY(dalloc(h, &h->d_w, h->n_w));
+  bind_weights(h);
+  TRY(dalloc(h, &h->d_raw, B * Tr));
+  TRY(dalloc(h, &h->d_ev, B * Te * 5));
+  TRY(dalloc(h, &h->mask, B * Tm));
+  const int npp = c.enc_depth > 2 ? 2 : (c.enc_depth > 1 ? 1 : 0);
+  for (int p = 0; p < npp; ++p) {
+    if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
+    if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
+  }
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->xw, B * Tx * 2 * RV_G));
+  for (int st = 0; st < 2; ++st)
+    for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[st][k], B * RV_U));
+  TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
+  TRY(dalloc(h, &h->keys, B * Tm * RV_U));
+  DecState& d = h->dec_st;
+  TRY(dalloc(h, &d.xh, N * RV_E));
+  TRY(dalloc(h, &d.z, N * RV_G));
+  TRY(dalloc(h, &d.c, N * RV_U));
+  TRY(dalloc(h, &d.c_new, N * RV_U));
+  TRY(dalloc(h, &d.h_new, N * RV_U));
+  TRY(dalloc(h, &d.tok, N));
+  TRY(dalloc(h, &d.log_probs, N));
+  TRY(dalloc(h, &d.finished, N));
+  TRY(dalloc(h, &d.lengths, N));
+  TRY(dalloc(h, &d.step_ids, L * N));
+  TRY(dalloc(h, &d.parent_ids, L * N));
+  TRY(dalloc(h, &d.step_scores, L * N));
+  TRY(dalloc(h, &d.step_logits, L * N * V));
+  TRY(dalloc(h, &d.nfin, L + 1));
+  TRY(dalloc(h, &d.S_dev, 1));
+  TRY(dalloc(h, &h->out_tokens, B * L));
+  TRY(dalloc(h, &h->out2, B * L * V));
+#undef TRY
+#undef HIPTRY
+  *out = h;
+  return RV_OK;
+}
+
+void rv_destroy(rv_handle h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : h->ev_pool) hipEventDestroy(e);
+  if (h->step_align) hipFree(h->step_align);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+size_t rv_weight_count(rv_handle h) { return h ? h->n_w : 0; }
+
+int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
+  if (!h) return RV_EINVAL;
+  if (!blob) return fail(h, RV_EINVAL, "null weight blob");
+  if (n_floats != h->n_w) return fail(h, RV_EINVAL, "weight blob has %zu floats, config needs %zu", n_floats, h->n_w);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMemcpyAsync(h->d_w, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->loaded = true;
+  return RV_OK;
+}
+
+int rv_beam_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                   int32_t W, int32_t L, int32_t* tokens, float* scores, int32_t* S_out) {
+  return run(h, raw, event, false, B, T_r, T_e, W, L, false, tokens, scores, false, S_out);
+}
+int rv_beam_search_dev(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                       int32_t W, int32_t L, int32_t* tokens, float* scores, int32_t* S_out) {
+  return run(h, raw, event, true, B, T_r, T_e, W, L, false, tokens, scores, true, S_out);
+}
+int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                     int32_t L, int32_t* tokens, float* logits, int32_t* S_out) {
+  return run(h, raw, event, false, B, T_r, T_e, 1, L, true, tokens, logits, false, S_out);
+}
+int rv_greedy_search_dev(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                         int32_t L, int32_t* tokens, float* logits, int32_t* S_out) {
+  return run(h, raw, event, true, B, T_r, T_e, 1, L, true, tokens, logits, true, S_out);
+}
+
+int rv_set_option(rv_handle h, const char* key, int32_t value) {
+  if (!h || !key) return RV_EINVAL;
+  if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
+  else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
+  else if (!strcmp(key, "profile")) h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else return fail(h, RV_EINVAL, "unknown option '%s'", key);
+  return RV_OK;
+}
+
+int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, size_t* n_written) {
+  if (!h || !name || !n_written) return RV_EINVAL;
+  const size_t B = h->lB, W = h->lW, Tm = h->lTm, S = h->lS, V = h->cfg.vocab;
+  const void* src = nullptr; size_t n = 0; int kind = 0;   // 0 f32, 1 i32, 2 u8
+  const DecState& d = h->dec_st;
+  if (!strcmp(name, "enc_output")) { src = h->enc_out; n = B * Tm * RV_E; }
+  else if (!strcmp(name, "mask")) { src = h->mask; n = B * Tm; kind = 2; }
+  else if (!strcmp(name, "keys")) { src = h->keys; n = B * Tm * RV_U; }
+  else if (!strcmp(name, "step_ids")) { src = d.step_ids; n = S * B * W; kind = 1; }
+  else if (!strcmp(name, "parent_ids")) { src = d.parent_ids; n = S * B * W; kind = 1; }
+  else if (!strcmp(name, "step_scores")) { src = d.step_scores; n = S * B * W; }
+  else if (!strcmp(name, "step_logits")) {
+    if (!h->ltaps && !h->lgreedy) return fail(h, RV_ESTATE, "step_logits needs option debug_taps=1");
+    src = d.step_logits; n = S * B * W * V;
+  } else if (!strcmp(name, "step_alignments")) {
+    if (!h->ltaps) return fail(h, RV_ESTATE, "step_alignments needs option debug_taps=1");
+    src = h->step_align; n = S * B * W * Tm;
+  } else return fail(h, RV_EINVAL, "unknown tensor '%s'", name);
+  *n_written = n;
+  if (n == 0) return RV_OK;
+  if (!dst || dst_floats < n) return fail(h, RV_EINVAL, "tensor '%s' needs %zu floats, buffer holds %zu", name, n, dst_floats);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (kind == 0) {
+    HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToHost));
+  } else if (kind == 1) {
+    std::vector<int32_t> tmp(n);
+    HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)tmp[i];
+  } else {
+    std::vector<uint8_t> tmp(n);
+    HIPCHK(h, hipMemcpy(tmp.data(), src, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)tmp[i];
+  }
+  return RV_OK;
+}
+
+int rv_get_profile(rv_handle h, const char* kernel, double* total_ms, int64_t* launches) {
+  if (!h || !kernel || !total_ms || !launches) return RV_EINVAL;
+  auto it = h->prof.find(kernel);
+  if (it == h->prof.end()) { *total_ms = 0; *launches = 0; return RV_OK; }
+  *total_ms = it->second.ms; *launches = it->second.n;
+  return RV_OK;
+}
+
+int rv_profile_names(rv_handle h, char* dst, size_t dst_bytes) {
+  if (!h || !dst || dst_bytes == 0) return RV_EINVAL;
+  std::string s;
+  for (auto& kv : h->prof) { if (!s.empty()) s += ';'; s += kv.first; }
+  if (s.size() + 1 > dst_bytes) return fail(h, RV_EINVAL, "name buffer too small (%zu needed)", s.size() + 1);
+  memcpy(dst, s.c_str(), s.size() + 1);
+  return RV_OK;
+}
+
+int rv_reset_profile(rv_handle h) {
+  if (!h) return RV_EINVAL;
+  h->prof.clear();
+  return RV_OK;
+}
+
+}  // extern "C"

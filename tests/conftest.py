@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def rv():
+    import ravvent_basecaller_amd
+    return ravvent_basecaller_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ravvent_oracle
+    return ravvent_oracle
