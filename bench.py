@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Ravvent hot path (Basecaller.beam_search_prediction) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one slab of synthetic chunks per GPU: workload C3 of
+BASELINE.json (joint raw+event mode, 300-sample raw windows + 30 events, beam 5, 256 chunks,
+max_output_len 48), inputs resident in HBM before the timed region, outputs left in HBM; with
+N>1 every rank decodes its own slab (weak scaling, chunks shard embarrassingly) and one RCCL
+all-gather of the [B,L-1] tokens+scores closes each step.  Rank 0 prints ONE JSON line.
+
+metric: kbases/s = chunks/s * 6 bases per chunk / 1000 (stride 6 events => ~6 new bases per chunk,
+/root/reference/ravvent_performance_evaluator.py:16); chunks/s is reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BASES_PER_CHUNK = 6
+PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_flops(kernel, B, T_r, T_e, W, S):
+    """Algorithmic FLOPs of ONE launch of `kernel` (2 per MAC, pointwise ignored)."""
+    Tm = T_r + T_e
+    rec = 2 * 128 * 512 * 2            # recurrent product, both directions, per chunk-step
+    return {
+        "lstm_rec_raw_l0": B * T_r * (rec + 2 * 1 * 512 * 2),
+        "lstm_rec_event_l0": B * T_e * (rec + 2 * 5 * 512 * 2),
+        "lstm_rec_raw_l1p": B * T_r * rec,
+        "lstm_rec_event_l1p": B * T_e * rec,
+        "gemm_inproj_raw": B * T_r * 256 * 512 * 2,      # one direction per launch
+        "gemm_inproj_event": B * T_e * 256 * 512 * 2,
+        "gemm_keys": B * Tm * 256 * 128 * 2,
+        "decode_graph": B * W * S * (369408 + 768 * Tm),
+    }.get(kernel)
+
+
+def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=1024):
+    """The C restatement of the oracle (oracle/ravvent_cpu.c, 'port') timed on this host's cores
+    on a bounded sample of the same workload."""
+    from oracle import cpu_port                       # checker / baseline only
+    raw, ev, _ = rv.synthetic.make_slab(sample_chunks, T_r, T_e, seed=100)
+    blob = rv.weights.pack(cfg, flat)
+    cores = cpu_port.max_threads()
+    cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, raw[:32], ev[:32], W, L)   # warm-up
+    t0 = time.perf_counter()
+    tok, _ = cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, raw, ev, W, L)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_chunks / dt * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
+            "chunks_per_s": round(sample_chunks / dt, 2), "cores": cores, "kind": "port",
+            "sample": f"{sample_chunks} chunks of the same workload (joint {T_r}+{T_e}, beam {W}, L {L}), "
+                      f"{dt:.1f} s wall, S={tok.shape[1]}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step (C3: 256)")
+    ap.add_argument("--raw-len", type=int, default=300)
+    ap.add_argument("--event-len", type=int, default=30)
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--max-output-len", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ravvent_basecaller_amd as rv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, T_r, T_e, W, L = args.batch, args.raw_len, args.event_len, args.beam, args.max_output_len
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", rv.data_loader.INPUT_PADDING,
+                       encoder_depth=2, decoder_depth=1, rnn_type="bilstm", attention_type="luong",
+                       beam_width=W, device=local, max_batch=B, max_raw_len=T_r, max_event_len=T_e,
+                       max_output_len=L)
+    flat = bc.init_random_weights(seed=22)            # Keras-default initialisers, seed as ravvent.py:9
+    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=rank)
+    d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
+    gathered = None
+    if world > 1:
+        gathered = (torch.empty((world * B, L - 1), dtype=torch.int32, device=dev),
+                    torch.empty((world * B, L - 1), dtype=torch.float32, device=dev))
+
+    def step():
+        tok, sc = bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
+        if world > 1:   # the path's single exchange: gather every rank's calls (RCCL over xGMI)
+            S = tok.shape[1]
+            pt = torch.zeros((B, L - 1), dtype=torch.int32, device=dev); pt[:, :S] = tok
+            ps = torch.zeros((B, L - 1), dtype=torch.float32, device=dev); ps[:, :S] = sc
+            dist.all_gather_into_tensor(gathered[0], pt)
+            dist.all_gather_into_tensor(gathered[1], ps)
+        return tok, sc
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    bc.set_option("profile", 1)       # hipEvents on the library's stream, live in the timed region
+    bc.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok, sc = step()
+    fence()
+    dt = time.perf_counter() - t0
+    S = int(tok.shape[1])
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = bc.profile()
+
+    if rank == 0:
+        chunks_per_s = world * B * args.steps / dt
+        # dominant kernel = largest accumulated device time among the profiled launches
+        name, (ms, n) = max(prof.items(), key=lambda kv: kv[1][0])
+        fl = algorithmic_flops(name, B, T_r, T_e, W, S)
+        avg_ms = ms / max(n, 1)
+        achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": n, "flops_per_launch": fl, "traffic": None}
+        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                roof["traffic"] = json.load(f).get(name)
+        total_ms = sum(v[0] for v in prof.values())
+        out = {
+            "metric": "kbases/s, raw+event joint mode, beam=5 (hot path: beam_search_prediction)",
+            "value": round(chunks_per_s * BASES_PER_CHUNK / 1000.0, 3), "unit": "kbases/s",
+            "chunks_per_s": round(chunks_per_s, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: joint raw+event, T_raw={T_r}, T_event={T_e}, beam={W}, "
+                                   f"{B} chunks/GPU/step, max_output_len={L}, enc_depth=2, dec_depth=1, units=128, luong",
+                       "decode_steps": S, "weights": "random-init (Keras defaults, seed 22)",
+                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step" if world > 1 else "")},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+            "device_ms_per_step": round(total_ms / args.steps, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(rv, bc.cfg, flat, T_r, T_e, W, L, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    bc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
