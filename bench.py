@@ -123,8 +123,11 @@ def main():
     bc.reset_profile()
     fence()
     t0 = time.perf_counter()
+    per_step = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         tok, sc = step()
+        per_step.append(time.perf_counter() - ts)
     fence()
     dt = time.perf_counter() - t0
     S = int(tok.shape[1])
@@ -164,6 +167,7 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
             "device_ms_per_step": round(total_ms / args.steps, 4),
+            "step_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rv, bc.cfg, flat, T_r, T_e, W, L, args.cpu_sample)

@@ -46,24 +46,116 @@ __global__ void k_dec_init(DecState d) {
   if (idx < d.L) d.nfin[idx] = 0;
 }
 
-__global__ void k_dec_gates(DecState d, int step) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D1 -- decoder LSTM cell, fused: pre-activations on v_mfma_f32_16x16x4_f32 + gate math.
+// z = [attention | h] . [W_dec[V:] ; U_dec] + W_dec[token] + b  (cell input = concat(one_hot, attention),
+// SURVEY.md A.4; the one-hot product is a row gather).
+// Workgroup = 64 beam rows x 16 units x 4 gates, K = 256 in one shot: the 64 KB activation panel and
+// the 64 KB weight panel (pre-transposed to [col][k] at load time, so both panels are straight row
+// copies) are pulled into LDS with every load in flight, ONE barrier, then each of the 8 waves runs
+// 2 x 64 MFMAs (16 rows x one gate's 16 units per tile, operands read as float4 along k) and the
+// four gate tiles meet in LDS for the cell update.  Operand re-reads from L2: x8 for activations,
+// x20 for weights (vs x32 / x80 for the register-only version this replaces).
+constexpr int CELL_LD = 260;                       // padded row length of the LDS panels (floats)
+constexpr int CELL_LDS_FLOATS = 2 * 64 * CELL_LD + 4 * 64 * 17;
+__global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __restrict__ WcatT,
+                                                  const float* __restrict__ Wtok, const float* __restrict__ bias,
+                                                  int step) {
   if (step > 0 && d.nfin[step - 1] >= d.B) return;
+  extern __shared__ __align__(16) float csm[];
+  float* As = csm;                        // [64 rows][260]
+  float* Bs = csm + 64 * CELL_LD;         // [64 cols = 4 gates x 16 units][260]
+  float* zs = csm + 2 * 64 * CELL_LD;     // [4 gates][64 rows][17]
   const int N = d.B * d.W;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * RV_U) return;
-  const int n = idx / RV_U, j = idx % RV_U;
-  const float* z = d.z + (size_t)n * RV_G + j;
-  const float ig = rv_sigmoid(z[0]), fg = rv_sigmoid(z[RV_U]);
-  const float gg = rv_tanh(z[2 * RV_U]), og = rv_sigmoid(z[3 * RV_U]);
-  const float c2 = fmaf(fg, d.c[idx], ig * gg);
-  d.c_new[idx] = c2;
-  d.h_new[idx] = og * rv_tanh(c2);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r0 = blockIdx.y * 64, u0 = blockIdx.x * 16;
+  {
+    float4 ra[8], rb[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;      // 64 float4 per 1 KB row
+      const int n = min(r0 + row, N - 1);
+      ra[p] = *reinterpret_cast<const float4*>(d.xh + (size_t)n * RV_E + 4 * c4);
+      const int col = (row >> 4) * RV_U + u0 + (row & 15);               // panel row = gate*16 + unit
+      rb[p] = *reinterpret_cast<const float4*>(WcatT + (size_t)col * RV_E + 4 * c4);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<float4*>(As + row * CELL_LD + 4 * c4) = ra[p];
+      *reinterpret_cast<float4*>(Bs + row * CELL_LD + 4 * c4) = rb[p];
+    }
+  }
+  __syncthreads();
+  const int rq = wv & 3, gh = wv >> 2;            // wave = 16-row quarter x gate pair
+  const int li = lane & 15, kq = lane >> 4;       // lane group kq supplies k in [64kq, 64kq+64)
+  const float4* ap = reinterpret_cast<const float4*>(As + (16 * rq + li) * CELL_LD + 64 * kq);
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int g = 2 * gh + gi;
+    const float4* bp = reinterpret_cast<const float4*>(Bs + (16 * g + li) * CELL_LD + 64 * kq);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 av = ap[i], bv = bp[i];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+    }
+    // C/D map of the 16x16 tile: col = lane & 15, row = 4*(lane >> 4) + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[(g * 64 + 16 * rq + 4 * kq + r) * 17 + li] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 512 * p, row = idx >> 4, un = idx & 15;
+    const int n = r0 + row;
+    if (n < N) {
+      const int col = u0 + un;
+      const float* wt = Wtok + (size_t)d.tok[n] * RV_G + col;
+      const float zi = zs[(0 * 64 + row) * 17 + un] + wt[0] + bias[col];
+      const float zf = zs[(1 * 64 + row) * 17 + un] + wt[RV_U] + bias[RV_U + col];
+      const float zg = zs[(2 * 64 + row) * 17 + un] + wt[2 * RV_U] + bias[2 * RV_U + col];
+      const float zo = zs[(3 * 64 + row) * 17 + un] + wt[3 * RV_U] + bias[3 * RV_U + col];
+      const float c2 = fmaf(rv_sigmoid(zf), d.c[(size_t)n * RV_U + col], rv_sigmoid(zi) * rv_tanh(zg));
+      d.c_new[(size_t)n * RV_U + col] = c2;
+      d.h_new[(size_t)n * RV_U + col] = rv_sigmoid(zo) * rv_tanh(c2);
+    }
+  }
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row; every lane ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp<0x141>(v);   // row_half_mirror
+  v += dpp<0x140>(v);   // row_mirror
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
+}
+// wave-uniform max via DPP inside the four 16-lane rows + readlane across them (no LDS round trips)
+__device__ __forceinline__ float wave_max_fast(float v) {
+  v = fmaxf(v, dpp<0xB1>(v));
+  v = fmaxf(v, dpp<0x4E>(v));
+  v = fmaxf(v, dpp<0x141>(v));
+  v = fmaxf(v, dpp<0x140>(v));
+  const int vi = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), b = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), e = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, e));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -72,21 +164,46 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 constexpr int WB = RV_MAX_BEAM;
+constexpr int ATT_THREADS = 512;
 
-__global__ __launch_bounds__(256) void k_dec_attend(DecState d, int step) {
+// LDS carve-up of k_dec_attend (floats), shared with the host-side size computation
+struct AttLds {
+  int q, pq, sc, al, part, hcT, att, lg, total;
+  __host__ __device__ AttLds(int W, int TmP) {
+    int o = 0;
+    q = o; o += W * RV_U;
+    pq = o; o += W * RV_U;
+    sc = o; o += W * TmP;
+    al = o; o += TmP * WB;
+    part = o; o += 8 * W * RV_E;          // context partials [8][W][256]; reused as [4][W][128] by phase E
+    hcT = o; o += (RV_U + RV_E) * WB;     // [h ; context] k-major, beam-minor
+    att = o; o += W * RV_U;
+    lg = o; o += WB * RV_MAX_VOCAB;
+    total = o;
+  }
+};
+
+// TB / TD: compile-time trip counts of the score / context sweeps (T_m <= 32*TB and <= 8*TD), so every
+// load of a sweep is issued before its first use (the kernel is latency-bound, not bandwidth-bound).
+template <int W, int TB, int TD>
+__global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step) {
   extern __shared__ __align__(16) float dsm[];
-  const int Tm = d.Tm, W = d.W, V = d.V;
+  const int Tm = d.Tm, V = d.V;
   const int TmP = (Tm + 3) & ~3;
-  float* sc = dsm;                 // [WB][TmP]   scores, then exp()
-  float* al = dsm + WB * TmP;      // [TmP][WB]   alignments, beam-minor for the context sweep
-  __shared__ __align__(16) float q[WB][RV_U];
-  __shared__ __align__(16) float pq[WB][RV_U];
-  __shared__ __align__(16) float ctx[WB][RV_E];
-  __shared__ __align__(16) float part[WB][2][RV_U];
-  __shared__ __align__(16) float att[WB][RV_U];
-  __shared__ float lg[WB][RV_MAX_VOCAB];
-  __shared__ float tot[WB * RV_MAX_VOCAB];
+  const AttLds L(W, TmP);
+  float* q = dsm + L.q;        // [W][128]
+  float* pq = dsm + L.pq;      // [W][128]
+  float* sc = dsm + L.sc;      // [W][TmP]
+  float* al = dsm + L.al;      // [TmP][WB]
+  float* part = dsm + L.part;
+  float* hcT = dsm + L.hcT;    // [384][WB]
+  float* att = dsm + L.att;    // [W][128]
+  float* lg = dsm + L.lg;      // [WB][8]
   __shared__ int s_parent[WB];
+  __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];   // W_fc [128][V] then b_fc [V]
+  __shared__ float s_cnew[WB * RV_U];
+  __shared__ float s_lprob[WB];
+  __shared__ int s_fin[WB], s_len[WB];
 
   const int b = blockIdx.x, tid = threadIdx.x;
   if (step > 0 && d.nfin[step - 1] >= d.B) {      // whole batch finished earlier: propagate
@@ -95,46 +212,91 @@ __global__ __launch_bounds__(256) void k_dec_attend(DecState d, int step) {
   }
   const size_t row0 = (size_t)b * W;
 
-  // ---- A: query = cell output h of every beam
-  for (int i = tid; i < W * RV_U; i += 256) q[i >> 7][i & 127] = d.h_new[row0 * RV_U + i];
-  __syncthreads();
-  if (d.attention == 1) {   // Bahdanau: processed query = q . W_q
-    const int jj = tid & 127, half = tid >> 7;
-    float acc[WB];
+  // ---- streaming loads first: nothing below depends on them until phases B / D, and the kernel
+  //      is HBM-bound (keys + values = 1.5 KB per memory step per chunk), so the stream must start
+  //      at entry and run under the small phases.  Issue order = completion order (vmcnt is
+  //      in-order): keys (phase B) before values (phase D).
+  const int sub = tid & 15, grp = tid >> 4;       // B: a DPP row (16 lanes) shares one memory step
+  const int cg = tid & 63, tg = tid >> 6;         // D: thread = (4 columns, 1 of 8 interleaved t-groups)
+  constexpr int TD1c = W <= 5 ? 16 : 6;           // value rows in flight beside the keys (VGPR budget)
+  constexpr int TD1 = TD < TD1c ? TD : TD1c;
+  float4 k0[TB], k1[TB];
+  uint8_t mk[TB];
+  float4 vv[TD];
+  {
+    const float* kbase = d.keys + (size_t)b * Tm * RV_U + 8 * sub;
+    const uint8_t* mrow = d.mask + (size_t)b * Tm;
 #pragma unroll
-    for (int w = 0; w < WB; ++w) acc[w] = 0.f;
-    for (int k = half * 64; k < half * 64 + 64; ++k) {
+    for (int u = 0; u < TB; ++u) {
+      const int t = min(grp + 32 * u, Tm - 1);
+      const float4* kp = reinterpret_cast<const float4*>(kbase + (size_t)t * RV_U);
+      k0[u] = kp[0]; k1[u] = kp[1];
+      mk[u] = mrow[t];
+    }
+    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * cg;
+#pragma unroll
+    for (int u = 0; u < TD1; ++u) {
+      const int t = min(tg + 8 * u, Tm - 1);
+      vv[u] = *reinterpret_cast<const float4*>(vbase + (size_t)t * RV_E);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- A: one round of small loads: query = cell output h of every beam (also the first 128 rows
+  //         of hcT), the new cell states, the beam bookkeeping and the output layer -> LDS
+  for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
+    const float v = d.h_new[row0 * RV_U + i];
+    q[i] = v;
+    hcT[(i & 127) * WB + (i >> 7)] = v;
+    s_cnew[i] = d.c_new[row0 * RV_U + i];
+  }
+  for (int i = tid; i < RV_U * V; i += ATT_THREADS) s_wfc[i] = d.W_fc[i];
+  if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
+  if (tid < W) {
+    s_fin[tid] = d.finished[row0 + tid];
+    s_lprob[tid] = d.log_probs[row0 + tid];
+    s_len[tid] = d.lengths[row0 + tid];
+  }
+  __syncthreads();
+  if (d.dbg_stop == 1) return;
+  if (d.attention == 1) {   // Bahdanau: processed query = q . W_q ; thread = (column, K quarter)
+    const int jj = tid & 127, kq = tid >> 7;
+    float acc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) acc[w] = 0.f;
+    for (int k = kq * 32; k < kq * 32 + 32; ++k) {
       const float wq = d.W_q[k * RV_U + jj];
 #pragma unroll
-      for (int w = 0; w < WB; ++w) acc[w] = fmaf(q[w][k], wq, acc[w]);
+      for (int w = 0; w < W; ++w) acc[w] = fmaf(q[w * RV_U + k], wq, acc[w]);
     }
 #pragma unroll
-    for (int w = 0; w < WB; ++w) part[w][half][jj] = acc[w];
+    for (int w = 0; w < W; ++w) part[(kq * W + w) * RV_U + jj] = acc[w];
     __syncthreads();
     if (tid < RV_U)
 #pragma unroll
-      for (int w = 0; w < WB; ++w) pq[w][tid] = part[w][0][tid] + part[w][1][tid];
+      for (int w = 0; w < W; ++w)
+        pq[w * RV_U + tid] = (part[(0 * W + w) * RV_U + tid] + part[(1 * W + w) * RV_U + tid]) +
+                             (part[(2 * W + w) * RV_U + tid] + part[(3 * W + w) * RV_U + tid]);
     __syncthreads();
   }
 
-  // ---- B: scores.  16 lanes share one memory step t (8 key columns each), 16 steps in flight.
+  // ---- B: scores from the keys already in registers
   {
-    const int sub = tid & 15, grp = tid >> 4;
-    float qr[WB][8], vr[8];
+    float qr[W][8], vr[8];
+    const float* qsrc = d.attention == 1 ? pq : q;
 #pragma unroll
-    for (int w = 0; w < WB; ++w)
+    for (int w = 0; w < W; ++w)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) qr[w][i] = d.attention == 1 ? pq[w][8 * sub + i] : q[w][8 * sub + i];
+      for (int i = 0; i < 8; ++i) qr[w][i] = qsrc[w * RV_U + 8 * sub + i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) vr[i] = d.attention == 1 ? d.v_att[8 * sub + i] : 0.f;
-    for (int t = grp; t < Tm; t += 16) {
-      const float4* kp = reinterpret_cast<const float4*>(d.keys + ((size_t)b * Tm + t) * RV_U + 8 * sub);
-      const float4 k0 = kp[0], k1 = kp[1];
-      const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-      const bool live = d.mask[(size_t)b * Tm + t] != 0;
 #pragma unroll
-      for (int w = 0; w < WB; ++w) {
-        if (w >= W) break;
+    for (int u = 0; u < TB; ++u) {
+      const int t = grp + 32 * u;
+      const float kk[8] = {k0[u].x, k0[u].y, k0[u].z, k0[u].w, k1[u].x, k1[u].y, k1[u].z, k1[u].w};
+      float mine = 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
         float p = 0.f;
         if (d.attention == 1) {
 #pragma unroll
@@ -143,18 +305,30 @@ __global__ __launch_bounds__(256) void k_dec_attend(DecState d, int step) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) p = fmaf(kk[i], qr[w][i], p);
         }
-        p += __shfl_xor(p, 8, 16); p += __shfl_xor(p, 4, 16);
-        p += __shfl_xor(p, 2, 16); p += __shfl_xor(p, 1, 16);
-        if (sub == 0) sc[w * TmP + t] = live ? p : -INFINITY;    // _maybe_mask_score
+        p = row16_sum(p);
+        mine = sub == w ? p : mine;
       }
+      if (t < Tm && sub < W) sc[sub * TmP + t] = mk[u] ? mine : -INFINITY;   // _maybe_mask_score
     }
   }
+  if (d.dbg_stop == 2) return;
+  // ---- D (loads, second part): the rest of the value rows, now that the key registers are free
+  if (TD > TD1) {
+    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * cg;
+#pragma unroll
+    for (int u = TD1; u < TD; ++u) {
+      const int t = min(tg + 8 * u, Tm - 1);
+      vv[u] = *reinterpret_cast<const float4*>(vbase + (size_t)t * RV_E);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
   // ---- C: softmax over T_m, one wave per beam
   {
     const int lane = tid & 63, wv = tid >> 6;
-    for (int w = wv; w < W; w += 4) {
+    if (wv < W) {
+      const int w = wv;
       float m = -INFINITY;
       for (int t = lane; t < Tm; t += 64) m = fmaxf(m, sc[w * TmP + t]);
       m = wave_max(m);
@@ -171,169 +345,218 @@ __global__ __launch_bounds__(256) void k_dec_attend(DecState d, int step) {
         if (d.step_align) d.step_align[(((size_t)step * d.B + b) * W + w) * Tm + t] = a;
       }
     }
-    for (int i = tid; i < Tm * WB; i += 256)
-      if ((i & (WB - 1)) >= W) al[i] = 0.f;
   }
   __syncthreads();
 
-  // ---- D: context = sum_t alpha_t * values_t ; thread = output column
+  if (d.dbg_stop == 3) return;
+  // ---- D (math): context = sum_t alpha_t * values_t
   {
-    float acc[WB];
+    f2 acc[W][2];
 #pragma unroll
-    for (int w = 0; w < WB; ++w) acc[w] = 0.f;
-    const float* vp = d.values + (size_t)b * Tm * RV_E + tid;
-#pragma unroll 4
-    for (int t = 0; t < Tm; ++t) {
-      const float v = vp[(size_t)t * RV_E];
-      const float4 a0 = *reinterpret_cast<const float4*>(&al[t * WB]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&al[t * WB + 4]);
-      acc[0] = fmaf(a0.x, v, acc[0]); acc[1] = fmaf(a0.y, v, acc[1]);
-      acc[2] = fmaf(a0.z, v, acc[2]); acc[3] = fmaf(a0.w, v, acc[3]);
-      acc[4] = fmaf(a1.x, v, acc[4]); acc[5] = fmaf(a1.y, v, acc[5]);
-      acc[6] = fmaf(a1.z, v, acc[6]); acc[7] = fmaf(a1.w, v, acc[7]);
+    for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+      const int t = tg + 8 * u;
+      if (t < Tm) {
+        float a[WB];
+        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(&al[t * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(&al[t * WB + 4]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].x, vv[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].z, vv[u].w}, acc[w][1]);
+        }
+      }
     }
 #pragma unroll
-    for (int w = 0; w < WB; ++w) ctx[w][tid] = acc[w];
+    for (int w = 0; w < W; ++w)
+      *reinterpret_cast<float4*>(&part[((tg * W + w) * RV_E) + 4 * cg]) =
+          make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+  }
+  __syncthreads();
+  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction of the 8 partials
+    const int w = i >> 8, col = i & 255;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[(g * W + w) * RV_E + col];
+    hcT[(RV_U + col) * WB + w] = s;
   }
   __syncthreads();
 
+  if (d.dbg_stop == 4) return;
   // ---- E: attention = [h ; context] . W_att   (Dense, no bias, no activation)
+  //         thread = (4 output columns, 1 of 16 K-groups of 24 rows); 24 float4 weight loads in flight
   {
-    const int dd = tid & 127, half = tid >> 7;
-    float acc[WB];
+    const int d4 = tid & 31, kg = tid >> 5;
+    float4 wv[24];
+    const float* wa = d.W_att + (size_t)(24 * kg) * RV_U + 4 * d4;
 #pragma unroll
-    for (int w = 0; w < WB; ++w) acc[w] = 0.f;
-    for (int k = half * 192; k < half * 192 + 192; ++k) {
-      const float wa = d.W_att[k * RV_U + dd];
+    for (int u = 0; u < 24; ++u) wv[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+    __builtin_amdgcn_sched_barrier(0);
+    f2 acc[W][2];
 #pragma unroll
-      for (int w = 0; w < WB; ++w) {
-        const float hv = k < RV_U ? q[w][k] : ctx[w][k - RV_U];
-        acc[w] = fmaf(hv, wa, acc[w]);
-      }
-    }
+    for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
 #pragma unroll
-    for (int w = 0; w < WB; ++w) part[w][half][dd] = acc[w];
-  }
-  __syncthreads();
-  if (tid < RV_U)
+    for (int u = 0; u < 24; ++u) {
+      float hv[WB];
+      *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + u) * WB]);
+      if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + u) * WB + 4]);
 #pragma unroll
-    for (int w = 0; w < WB; ++w) att[w][tid] = part[w][0][tid] + part[w][1][tid];
-  __syncthreads();
-
-  // ---- F: logits = attention . W_fc + b_fc
-  if (tid < W * V) {
-    const int w = tid / V, v = tid % V;
-    float acc = 0.f;
-    for (int k = 0; k < RV_U; ++k) acc = fmaf(att[w][k], d.W_fc[k * V + v], acc);
-    acc += d.b_fc[v];
-    lg[w][v] = acc;
-    if (d.step_logits) d.step_logits[(((size_t)step * d.B + b) * W + w) * V + v] = acc;
-  }
-  __syncthreads();
-
-  // ---- G: sampler / beam step (tiny: W*V <= 64 candidates)
-  if (tid == 0) {
-    const size_t o = ((size_t)step * d.B + b) * W;
-    if (d.greedy) {
-      int best = 0;
-      for (int v = 1; v < V; ++v) if (lg[0][v] > lg[0][best]) best = v;   // first max on ties
-      const bool fin = d.finished[row0] || best == d.end_token;
-      d.step_ids[o] = best; d.parent_ids[o] = 0; d.step_scores[o] = lg[0][best];
-      d.tok[row0] = best;
-      d.finished[row0] = fin;
-      s_parent[0] = 0;
-      if (fin) atomicAdd(&d.nfin[step], 1);
-    } else {
       for (int w = 0; w < W; ++w) {
-        float m = lg[w][0];
-        for (int v = 1; v < V; ++v) m = fmaxf(m, lg[w][v]);
-        float s = 0.f;
-        for (int v = 0; v < V; ++v) s += expf(lg[w][v] - m);
-        const float lse = logf(s);
-        const bool fin = d.finished[row0 + w] != 0;
-        const float lpw = d.log_probs[row0 + w];
-        for (int v = 0; v < V; ++v) {
-          const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (lg[w][v] - m) - lse;
-          tot[w * V + v] = lpw + lp;
-        }
+        acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].x, wv[u].y}, acc[w][0]);
+        acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].z, wv[u].w}, acc[w][1]);
       }
-      unsigned long long taken = 0ull;
-      int word[WB], par[WB], nlen[WB]; float val[WB]; bool nfin[WB];
-      bool all = true;
-      for (int k = 0; k < W; ++k) {
-        int best = -1;
-        for (int cnd = 0; cnd < W * V; ++cnd) {
-          if (taken >> cnd & 1ull) continue;
-          if (best < 0 || tot[cnd] > tot[best]) best = cnd;    // ties -> lower index
-        }
-        taken |= 1ull << best;
-        word[k] = best % V; par[k] = best / V; val[k] = tot[best];
-        const bool pf = d.finished[row0 + par[k]] != 0;
-        nfin[k] = pf || word[k] == d.end_token;
-        nlen[k] = d.lengths[row0 + par[k]] + (pf ? 0 : 1);
-        all = all && nfin[k];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_U + 4 * d4]) =
+          make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+  }
+  __syncthreads();
+  for (int i = tid; i < W * RV_U; i += ATT_THREADS) {      // fixed-order reduction of the 16 partials
+    const int w = i >> 7, col = i & 127;
+    float s0 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+    att[i] = s0;
+  }
+  __syncthreads();
+
+  if (d.dbg_stop == 5) return;
+  // ---- F: logits = attention . W_fc + b_fc ; one 16-lane row per (beam, token)
+  {
+    const int sub = tid & 15, o = tid >> 4;         // o < 32 outputs per pass
+    for (int ob = o; ob < W * V; ob += ATT_THREADS / 16) {
+      const int w = ob / V, v = ob % V;
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p = fmaf(att[w * RV_U + 8 * sub + i], s_wfc[(8 * sub + i) * V + v], p);
+      p = row16_sum(p) + s_wfc[RV_U * V + v];
+      if (sub == 0) {
+        lg[w * RV_MAX_VOCAB + v] = p;
+        if (d.step_logits) d.step_logits[(((size_t)step * d.B + b) * W + w) * V + v] = p;
       }
-      for (int k = 0; k < W; ++k) {
-        d.step_ids[o + k] = word[k]; d.parent_ids[o + k] = par[k]; d.step_scores[o + k] = val[k];
-        d.tok[row0 + k] = word[k];
-        d.log_probs[row0 + k] = val[k];
-        d.finished[row0 + k] = nfin[k];
-        d.lengths[row0 + k] = nlen[k];
-        s_parent[k] = par[k];
-      }
-      if (all) atomicAdd(&d.nfin[step], 1);
     }
   }
   __syncthreads();
 
+  if (d.dbg_stop == 6) return;
+  // ---- G: sampler / beam step, wave 0: lane = candidate (beam w, token v), W*V <= 64
+  if (tid < 64) {
+    const int lane = tid, w = lane / V, v = lane % V;
+    const bool cand = lane < W * V;
+    const size_t o = ((size_t)step * d.B + b) * W;
+    float val = -INFINITY;
+    if (d.greedy) {
+      if (cand) val = lg[v];
+    } else if (cand) {
+      float m = lg[w * RV_MAX_VOCAB];
+      for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
+      float ssum = 0.f;
+      for (int x = 0; x < V; ++x) ssum += expf(lg[w * RV_MAX_VOCAB + x] - m);
+      const float lse = logf(ssum);
+      const bool fin = s_fin[w] != 0;
+      const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (lg[w * RV_MAX_VOCAB + v] - m) - lse;
+      val = s_lprob[w] + lp;
+    }
+    // top-W by repeated wave max; ties -> lowest flat index (tf.math.top_k order)
+    bool taken = !cand;
+    int my_word = 0, my_par = 0; float my_val = 0.f;
+    for (int k = 0; k < W; ++k) {
+      const float mx = wave_max_fast(taken ? -INFINITY : val);
+      const unsigned long long hit = __ballot(!taken && (val == mx || mx == -INFINITY));
+      const int win = __ffsll((long long)hit) - 1;
+      const float wval = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), win));
+      if (lane == win) taken = true;
+      if (lane == k) { my_word = win % V; my_par = win / V; my_val = wval; }
+    }
+    bool nf = false; int nl = 0;
+    if (lane < W) {
+      if (d.greedy) {
+        nf = s_fin[0] != 0 || my_word == d.end_token;
+      } else {
+        const bool pf = s_fin[my_par] != 0;
+        nf = pf || my_word == d.end_token;
+        nl = s_len[my_par] + (pf ? 0 : 1);
+      }
+    }
+    const unsigned long long fmask = __ballot(lane < W && nf);
+    if (lane < W) {   // all reads of the old beam state happened above (same wave, program order)
+      d.step_ids[o + lane] = my_word; d.parent_ids[o + lane] = my_par; d.step_scores[o + lane] = my_val;
+      d.tok[row0 + lane] = my_word;
+      d.finished[row0 + lane] = nf;
+      if (!d.greedy) { d.log_probs[row0 + lane] = my_val; d.lengths[row0 + lane] = nl; }
+      s_parent[lane] = my_par;
+    }
+    if (lane == 0 && __popcll(fmask) == W) atomicAdd(&d.nfin[step], 1);
+  }
+  __syncthreads();
+
+  if (d.dbg_stop == 7) return;
   // ---- H: next-step state, gathered by parent beam: xh = [attention | h], c
-  for (int i = tid; i < W * RV_U; i += 256) {
+  for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
     const int w = i >> 7, e = i & 127, p = s_parent[w];
-    d.xh[(row0 + w) * RV_E + e] = att[p][e];
-    d.xh[(row0 + w) * RV_E + RV_U + e] = q[p][e];
-    d.c[(row0 + w) * RV_U + e] = d.c_new[(row0 + p) * RV_U + e];
+    d.xh[(row0 + w) * RV_E + e] = att[p * RV_U + e];
+    d.xh[(row0 + w) * RV_E + RV_U + e] = q[p * RV_U + e];
+    d.c[(row0 + w) * RV_U + e] = s_cnew[p * RV_U + e];
   }
 }
 
-__global__ void k_dec_finalize(DecState d, int32_t* tokens, float* out2) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.B) return;
-  const int steps = d.L - 1;
-  int S = steps;
-  for (int s = 0; s < steps; ++s)
-    if (d.nfin[s] >= d.B) { S = s + 1; break; }
-  if (b == 0) *d.S_dev = S;
+// One 64-thread workgroup per chunk: the chunk's [S,W] ids/parents are staged in LDS so the
+// serial gather_tree back-trace runs on LDS latency, not on dependent global loads.
+__global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens, float* out2) {
+  __shared__ int s_ids[64 * RV_MAX_BEAM], s_par[64 * RV_MAX_BEAM], s_tok[64];
+  __shared__ int s_S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int steps = d.L - 1, W = d.W, V = d.V;
+  if (tid == 0) {
+    int S = steps;
+    for (int s = 0; s < steps; ++s)
+      if (d.nfin[s] >= d.B) { S = s + 1; break; }
+    s_S = S;
+    if (b == 0) *d.S_dev = S;
+  }
+  __syncthreads();
+  const int S = s_S;
   int32_t* tk = tokens + (size_t)b * steps;
-  const int W = d.W, V = d.V;
   if (d.greedy) {
-    float* lo = out2 + (size_t)b * steps * V;
-    for (int s = 0; s < steps; ++s) {
+    for (int s = tid; s < steps; s += 64) {
       tk[s] = s < S ? d.step_ids[(size_t)s * d.B + b] : d.pad_token;
       for (int v = 0; v < V; ++v)
-        lo[s * V + v] = s < S ? d.step_logits[((size_t)s * d.B + b) * V + v] : 0.f;
+        out2[((size_t)b * steps + s) * V + v] = s < S ? d.step_logits[((size_t)s * d.B + b) * V + v] : 0.f;
     }
     return;
   }
-  // gather_tree for beam 0
-  int maxlen = 0;
-  for (int w = 0; w < W; ++w) maxlen = max(maxlen, d.lengths[(size_t)b * W + w]);
-  const int Lb = min(S, maxlen);
-  for (int s = 0; s < steps; ++s) tk[s] = s < S ? d.end_token : d.pad_token;
-  if (Lb > 0) {
-    tk[Lb - 1] = d.step_ids[((size_t)(Lb - 1) * d.B + b) * W];
-    int p = d.parent_ids[((size_t)(Lb - 1) * d.B + b) * W];
-    for (int t = Lb - 2; t >= 0; --t) {
-      tk[t] = d.step_ids[((size_t)t * d.B + b) * W + p];
-      p = d.parent_ids[((size_t)t * d.B + b) * W + p];
-    }
-    bool done = false;
-    for (int t = 0; t < Lb; ++t) {
-      if (done) tk[t] = d.end_token;
-      else if (tk[t] == d.end_token) done = true;
+  for (int i = tid; i < S * W; i += 64) {
+    const int s = i / W, w = i % W;
+    s_ids[i] = d.step_ids[((size_t)s * d.B + b) * W + w];
+    s_par[i] = d.parent_ids[((size_t)s * d.B + b) * W + w];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int maxlen = 0;
+    for (int w = 0; w < W; ++w) maxlen = max(maxlen, d.lengths[(size_t)b * W + w]);
+    const int Lb = min(S, maxlen);
+    for (int s = 0; s < S; ++s) s_tok[s] = d.end_token;
+    if (Lb > 0) {
+      s_tok[Lb - 1] = s_ids[(Lb - 1) * W];
+      int p = s_par[(Lb - 1) * W];
+      for (int t = Lb - 2; t >= 0; --t) {
+        s_tok[t] = s_ids[t * W + p];
+        p = s_par[t * W + p];
+      }
+      bool done = false;
+      for (int t = 0; t < Lb; ++t) {
+        if (done) s_tok[t] = d.end_token;
+        else if (s_tok[t] == d.end_token) done = true;
+      }
     }
   }
-  float* sco = out2 + (size_t)b * steps;
-  for (int s = 0; s < steps; ++s) sco[s] = s < S ? d.step_scores[((size_t)s * d.B + b) * W] : 0.f;
+  __syncthreads();
+  for (int s = tid; s < steps; s += 64) {
+    tk[s] = s < S ? s_tok[s] : d.pad_token;
+    out2[(size_t)b * steps + s] = s < S ? d.step_scores[((size_t)s * d.B + b) * W] : 0.f;
+  }
 }
 
 }  // namespace
@@ -347,15 +570,46 @@ void launch_dec_init(const DecState& d, hipStream_t s) {
   const int n = max(d.B * d.W, d.L);
   hipLaunchKernelGGL(k_dec_init, dim3((n + 255) / 256), dim3(256), 0, s, d);
 }
-void launch_dec_gates(const DecState& d, int step, hipStream_t s) {
-  const int n = d.B * d.W * RV_U;
-  hipLaunchKernelGGL(k_dec_gates, dim3((n + 255) / 256), dim3(256), 0, s, d, step);
+void launch_dec_cell(const DecState& d, const float* WcatT, const float* Wtok, const float* bias, int step,
+                     hipStream_t s) {
+  const int N = d.B * d.W;
+  const size_t shm = sizeof(float) * CELL_LDS_FLOATS;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + 63) / 64), dim3(512), shm, s, d, WcatT, Wtok, bias, step);
+}
+template <int W, int TB, int TD>
+static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {
+  const int TmP = (d.Tm + 3) & ~3;
+  const size_t shm = sizeof(float) * AttLds(W, TmP).total;
+  static size_t configured = 64 * 1024;
+  if (shm > configured) {   // > 64 KB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend<W, TB, TD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    configured = shm;
+  }
+  hipLaunchKernelGGL((k_dec_attend<W, TB, TD>), dim3(d.B), dim3(ATT_THREADS), shm, s, d, step);
+}
+template <int W>
+static void launch_attend_w(const DecState& d, int step, hipStream_t s) {
+  if (d.Tm <= 64) launch_attend_wt<W, 2, 8>(d, step, s);
+  else if (d.Tm <= 224) launch_attend_wt<W, 7, 28>(d, step, s);
+  else launch_attend_wt<W, 11, 44>(d, step, s);
 }
 void launch_dec_attend(const DecState& d, int step, hipStream_t s) {
-  const int TmP = (d.Tm + 3) & ~3;
-  const size_t shm = sizeof(float) * 2 * WB * TmP;
-  hipLaunchKernelGGL(k_dec_attend, dim3(d.B), dim3(256), shm, s, d, step);
+  switch (d.W) {
+    case 1: launch_attend_w<1>(d, step, s); break;
+    case 2: launch_attend_w<2>(d, step, s); break;
+    case 3: launch_attend_w<3>(d, step, s); break;
+    case 4: launch_attend_w<4>(d, step, s); break;
+    case 5: launch_attend_w<5>(d, step, s); break;
+    case 6: launch_attend_w<6>(d, step, s); break;
+    case 7: launch_attend_w<7>(d, step, s); break;
+    default: launch_attend_w<8>(d, step, s); break;
+  }
 }
 void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s) {
-  hipLaunchKernelGGL(k_dec_finalize, dim3((d.B + 63) / 64), dim3(64), 0, s, d, tokens, out2);
+  hipLaunchKernelGGL(k_dec_finalize, dim3(d.B), dim3(64), 0, s, d, tokens, out2);
 }

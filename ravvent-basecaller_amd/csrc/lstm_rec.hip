@@ -19,11 +19,11 @@
 
 namespace {
 
-__device__ __forceinline__ float quad_xor1(float v) {  // quad_perm [1,0,3,2]
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_xor2(float v) {  // quad_perm [2,3,0,1]
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {   // DPP quad_perm, CTRL = sel0 | sel1<<2 | sel2<<4 | sel3<<6
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
 template <int BT, int F>
@@ -38,15 +38,20 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
   const int b0 = blockIdx.x * BT;
   const int T = a.T;
 
-  // ---- recurrent kernel slice -> registers
-  float u[4][32];
+  // ---- recurrent kernel slice -> registers.  Slot r of lane kq holds gate (kq + r) & 3, so the
+  // quad reduce-scatter below lands gate kq's full sum in lane kq with three DPP adds and no selects.
+  // Slots are paired (0,1) / (2,3) for v_pk_fma_f32: plain v_fma_f32 runs at half the fp32 rate.
+  f2 u01[32], u23[32];
   {
     const float* Ud = a.U[dir] + (32 * kq) * RV_G + j;
+    const int g0 = kq * RV_U, g1 = ((kq + 1) & 3) * RV_U, g2 = ((kq + 2) & 3) * RV_U, g3 = ((kq + 3) & 3) * RV_U;
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) u[g][i] = Ud[i * RV_G + g * RV_U];
+    for (int i = 0; i < 32; ++i) {
+      u01[i] = f2{Ud[i * RV_G + g0], Ud[i * RV_G + g1]};
+      u23[i] = f2{Ud[i * RV_G + g2], Ud[i * RV_G + g3]};
+    }
   }
+  const float am = kq == 2 ? 2.f : 1.f;      // own gate: tanh (c~) for kq == 2, sigmoid otherwise
   // ---- layer-0 input kernel column for "my" gate (gate index = kq)
   float wx[F > 0 ? F : 1];
   float bx = 0.f;
@@ -96,6 +101,8 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
     }
     const float* hc = hs + cur * BT * RV_U;
     float* hn = hs + (cur ^ 1) * BT * RV_U;
+    // phase 1: gate pre-activations of every row (packed FMAs + quad reduce-scatter)
+    float z[BT];
 #pragma unroll
     for (int r = 0; r < BT; ++r) {
       float xv;
@@ -106,32 +113,44 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
       } else {
         xv = xc[r];
       }
-      float a0 = kq == 0 ? xv : 0.f, a1 = kq == 1 ? xv : 0.f;
-      float a2 = kq == 2 ? xv : 0.f, a3 = kq == 3 ? xv : 0.f;
+      f2 a01 = f2{xv, 0.f}, a23 = f2{0.f, 0.f};
       const float4* hp = reinterpret_cast<const float4*>(hc + r * RV_U + 32 * kq);
 #pragma unroll
       for (int i4 = 0; i4 < 8; ++i4) {
         const float4 hv = hp[i4];
-        a0 = fmaf(hv.x, u[0][4 * i4 + 0], a0); a1 = fmaf(hv.x, u[1][4 * i4 + 0], a1);
-        a2 = fmaf(hv.x, u[2][4 * i4 + 0], a2); a3 = fmaf(hv.x, u[3][4 * i4 + 0], a3);
-        a0 = fmaf(hv.y, u[0][4 * i4 + 1], a0); a1 = fmaf(hv.y, u[1][4 * i4 + 1], a1);
-        a2 = fmaf(hv.y, u[2][4 * i4 + 1], a2); a3 = fmaf(hv.y, u[3][4 * i4 + 1], a3);
-        a0 = fmaf(hv.z, u[0][4 * i4 + 2], a0); a1 = fmaf(hv.z, u[1][4 * i4 + 2], a1);
-        a2 = fmaf(hv.z, u[2][4 * i4 + 2], a2); a3 = fmaf(hv.z, u[3][4 * i4 + 2], a3);
-        a0 = fmaf(hv.w, u[0][4 * i4 + 3], a0); a1 = fmaf(hv.w, u[1][4 * i4 + 3], a1);
-        a2 = fmaf(hv.w, u[2][4 * i4 + 3], a2); a3 = fmaf(hv.w, u[3][4 * i4 + 3], a3);
+        a01 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u01[4 * i4 + 0], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u23[4 * i4 + 0], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u01[4 * i4 + 1], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u23[4 * i4 + 1], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u01[4 * i4 + 2], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u23[4 * i4 + 2], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u01[4 * i4 + 3], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u23[4 * i4 + 3], a23);
       }
-      // butterfly over the quad: every lane ends with the full sums of all four gates
-      a0 += quad_xor1(a0); a1 += quad_xor1(a1); a2 += quad_xor1(a2); a3 += quad_xor1(a3);
-      a0 += quad_xor2(a0); a1 += quad_xor2(a1); a2 += quad_xor2(a2); a3 += quad_xor2(a3);
-      const float ig = rv_sigmoid(a0), fg = rv_sigmoid(a1), gg = rv_tanh(a2), og = rv_sigmoid(a3);
+      // quad reduce-scatter: lane L takes slot 3 of lane L+1, slot 2 of lane L+2, slot 1 of lane L+3
+      float zz = a01.x + quad_perm<0x39>(a23.y);
+      zz += quad_perm<0x4E>(a23.x);
+      zz += quad_perm<0x93>(a01.y);
+      z[r] = zz;
+    }
+    // phase 2: one activation per lane (gate kq), all-gather inside the quad, cell update.
+    // All rows sit in one basic block so their dependent chains interleave.
+#pragma unroll
+    for (int r = 0; r < BT; ++r) {
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-am * z[r]));
+      const float act = fmaf(sg, am, 1.0f - am);
+      const float ig = quad_perm<0x00>(act), fg = quad_perm<0x55>(act);
+      const float gg = quad_perm<0xAA>(act), og = quad_perm<0xFF>(act);
       c[r] = fmaf(fg, c[r], ig * gg);
-      const float h = og * rv_tanh(c[r]);
-      hlast[r] = h;
-      if (kq == 0) {
-        hn[r * RV_U + j] = h;
+      hlast[r] = og * rv_tanh(c[r]);
+    }
+    // phase 3: publish h (LDS for the next step, global for the layer output)
+    if (kq == 0) {
+#pragma unroll
+      for (int r = 0; r < BT; ++r) {
+        hn[r * RV_U + j] = hlast[r];
         if (b0 + r < a.B)
-          a.out[((size_t)(b0 + r) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + j] = h;
+          a.out[((size_t)(b0 + r) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + j] = hlast[r];
       }
     }
     if (F == 0) {

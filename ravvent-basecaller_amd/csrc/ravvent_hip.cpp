@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -42,6 +43,7 @@ struct RvContext {
   bool loaded = false;
   std::vector<std::vector<LstmW>> enc[2];   // [enc][layer][dir]
   LstmW dec{};
+  float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
   // encoder buffers
@@ -220,18 +222,14 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
   }
 }
 
-void launch_decode_steps(RvContext* h, const DecState& d, const GemmArgs& cell, hipStream_t s, bool profiled) {
+void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool profiled) {
+  const float* Wcat = h->d_WcatT;
   for (int step = 0; step < d.L - 1; ++step) {
-    GemmArgs g = cell;
-    g.skip_flag = step > 0 ? d.nfin + (step - 1) : nullptr;
-    g.skip_when = d.B;
     if (profiled) {
-      { Scope sc(h, "gemm_dec_cell"); launch_gemm_f32(g, true, s); }
-      { Scope sc(h, "dec_gates"); launch_dec_gates(d, step, s); }
+      { Scope sc(h, "dec_cell"); launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s); }
       { Scope sc(h, "dec_attend"); launch_dec_attend(d, step, s); }
     } else {
-      launch_gemm_f32(g, true, s);
-      launch_dec_gates(d, step, s);
+      launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s);
       launch_dec_attend(d, step, s);
     }
   }
@@ -251,6 +249,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if (W < 1 || W > c.max_beam || W > RV_MAX_BEAM) return fail(h, RV_EINVAL, "beam width %d outside [1,%d]", W, std::min(c.max_beam, RV_MAX_BEAM));
   if (L < 1 || L > c.max_output_len) return fail(h, RV_EINVAL, "max_output_len=%d outside [1,%d]", L, c.max_output_len);
   if ((use_raw && !raw) || (use_ev && !ev)) return fail(h, RV_EINVAL, "missing input pointer for this mode");
+  if (T_r + T_e > 352) return fail(h, RV_EUNSUPPORTED, "attention memory of %d steps exceeds the 352 the decode kernel is built for", T_r + T_e);
+  if (L > 64) return fail(h, RV_EUNSUPPORTED, "max_output_len %d exceeds 64", L);
   if (!S_out || (B > 0 && L > 1 && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
   HIPCHK(h, hipSetDevice(c.device));
   h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps;
@@ -306,19 +306,13 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   HIPCHK(h, hipMemsetAsync(d.c, 0, sizeof(float) * N * RV_U, s));
   launch_dec_init(d, s);
 
-  GemmArgs cell{};
-  cell.A = d.xh; cell.lda = RV_E;
-  cell.Bm = h->dec.W + (size_t)V * RV_G; cell.ldb = RV_G;     // rows V..V+127 of W_dec, then U_dec: contiguous [256,512]
-  cell.C = d.z; cell.ldc = RV_G; cell.M = N; cell.N = RV_G; cell.K = RV_E;
-  cell.bias = h->dec.b; cell.gather_idx = d.tok; cell.gather_tab = h->dec.W; cell.ld_tab = RV_G;
-
   if (h->opt_graph && h->opt_profile != 2) {
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t graph = nullptr;
       HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      launch_decode_steps(h, d, cell, s, false);
+      launch_decode_steps(h, d, s, false);
       HIPCHK(h, hipStreamEndCapture(s, &graph));
       hipGraphExec_t exec = nullptr;
       HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -328,7 +322,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     Scope sc(h, "decode_graph");
     HIPCHK(h, hipGraphLaunch(it->second, s));
   } else {
-    launch_decode_steps(h, d, cell, s, h->opt_profile == 2);
+    launch_decode_steps(h, d, s, h->opt_profile == 2);
   }
 
   int32_t* tk = dev_out ? tokens : h->out_tokens;
@@ -391,6 +385,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
+  TRY(dalloc(h, &h->d_WcatT, (size_t)RV_G * RV_E));
   bind_weights(h);
   TRY(dalloc(h, &h->d_raw, B * Tr));
   TRY(dalloc(h, &h->d_ev, B * Te * 5));
@@ -406,6 +401,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
   TRY(dalloc(h, &h->keys, B * Tm * RV_U));
   DecState& d = h->dec_st;
+  if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);   // timing ablation only; results are invalid when set
   TRY(dalloc(h, &d.xh, N * RV_E));
   TRY(dalloc(h, &d.z, N * RV_G));
   TRY(dalloc(h, &d.c, N * RV_U));
@@ -450,6 +446,14 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
   if (n_floats != h->n_w) return fail(h, RV_EINVAL, "weight blob has %zu floats, config needs %zu", n_floats, h->n_w);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpyAsync(h->d_w, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  {   // derived layout for the decoder cell kernel: rows V..V+127 of W_dec followed by U_dec form a
+      // contiguous [256][512] matrix in the blob; the kernel wants it column-major ([512][256]).
+    const size_t off = (size_t)(h->dec.W - h->d_w) + (size_t)h->cfg.vocab * RV_G;
+    std::vector<float> t((size_t)RV_G * RV_E);
+    for (int k = 0; k < RV_E; ++k)
+      for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
+    HIPCHK(h, hipMemcpy(h->d_WcatT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->loaded = true;
   return RV_OK;
