@@ -117,10 +117,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     bc.set_option("profile", 1)       # hipEvents on the library's stream, live in the timed region
+    for _ in range(max(args.warmup, 1)):   # (>=1: graph capture and event pool are built here, not in the timed region)
+        step()
     bc.reset_profile()
+    import gc
+    gc.collect(); gc.disable()
     fence()
     t0 = time.perf_counter()
     per_step = []
@@ -130,12 +132,15 @@ def main():
         per_step.append(time.perf_counter() - ts)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     S = int(tok.shape[1])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = bc.profile()
+    if os.environ.get("RV_BENCH_VERBOSE"):
+        print("per-step ms:", " ".join(f"{x*1e3:.2f}" for x in per_step), file=sys.stderr)
 
     if rank == 0:
         chunks_per_s = world * B * args.steps / dt

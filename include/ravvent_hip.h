@@ -94,6 +94,8 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
 
 /* Options: "debug_taps" (0/1: keep per-step logits/alignments for rv_get_tensor),
  *          "use_graph"  (0/1: replay the decode loop from a captured hipGraph),
+ *          "flash_attend" (0/1, default 1: single-pass Luong attention over values only;
+ *                       0 = two-pass keys-then-values dataflow of the reference),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around
  *                       the graph as a whole; 2: no graph, events around every kernel). */
 int rv_set_option(rv_handle h, const char* key, int32_t value);

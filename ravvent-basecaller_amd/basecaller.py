@@ -170,8 +170,7 @@ class Basecaller:
         S = ctypes.c_int32(0)
         if on_dev:
             torch.cuda.current_stream(self.device).synchronize()   # inputs ready before the library's stream reads them
-            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
-            scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
+            tokens, scores = self._out_buffers("beam", B, steps, 1)
             rc = self._lib.rv_beam_search_dev(self._h, pr, pe, B, Tr, Te, W, L,
                                               ctypes.c_void_p(tokens.data_ptr()), ctypes.c_void_p(scores.data_ptr()),
                                               ctypes.byref(S))
@@ -194,8 +193,7 @@ class Basecaller:
         S = ctypes.c_int32(0)
         if on_dev:
             torch.cuda.current_stream(self.device).synchronize()
-            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
-            logits = torch.empty((B, steps, V), dtype=torch.float32, device=self.device)
+            tokens, logits = self._out_buffers("greedy", B, steps, V)
             rc = self._lib.rv_greedy_search_dev(self._h, pr, pe, B, Tr, Te, L,
                                                 ctypes.c_void_p(tokens.data_ptr()), ctypes.c_void_p(logits.data_ptr()),
                                                 ctypes.byref(S))
@@ -209,6 +207,18 @@ class Basecaller:
         self._check(rc, "rv_greedy_search")
         self.last_steps = S.value
         return tokens[:, :S.value], logits[:, :S.value]
+
+    def _out_buffers(self, kind, B, steps, V):
+        """Device output buffers are reused per shape (no allocator traffic in the hot loop); the
+        returned tensors are fresh views, valid until the next call with the same shape."""
+        key = (kind, B, steps, V)
+        cache = self.__dict__.setdefault("_outs", {})
+        if key not in cache:
+            cache.clear()
+            shape2 = (B, steps, V) if kind == "greedy" else (B, steps)
+            cache[key] = (torch.empty((B, steps), dtype=torch.int32, device=self.device),
+                          torch.empty(shape2, dtype=torch.float32, device=self.device))
+        return cache[key]
 
     def tokens_to_nuc_sequences(self, result_tokens):
         """basecaller.py:289-294"""

@@ -81,12 +81,14 @@ struct DecState {
   float* step_align;      // [L-1,B,W,Tm]  (debug) or nullptr
   int* nfin;              // [L] chunks-finished counter per step
   int* S_dev;             // [1]
+  long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)
 };
 void launch_dec_init(const DecState& d, hipStream_t s);
 void launch_dec_cell(const DecState& d, const float* WcatT /*[512,256] = ([W_dec[V:];U_dec])^T*/, const float* Wtok /*[V,512]*/,
                      const float* bias /*[512]*/, int step, hipStream_t s);
-void launch_dec_attend(const DecState& d, int step, hipStream_t s);
+// flash: single-pass Luong attend over `values` only (WmemT = W_mem^T [128,256]); else the two-pass kernel
+void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
 
 // ---------------------------------------------------------------- device math helpers

@@ -141,9 +141,22 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp<0x140>(v);   // row_mirror
   return v;
 }
+// value of lane n (0..7) of the caller's 16-lane row, in every lane of that row (DPP row_newbcast)
+__device__ __forceinline__ float row_bcast(float v, int n) {
+  switch (n) {
+    case 0: return dpp<0x150>(v); case 1: return dpp<0x151>(v); case 2: return dpp<0x152>(v);
+    case 3: return dpp<0x153>(v); case 4: return dpp<0x154>(v); case 5: return dpp<0x155>(v);
+    case 6: return dpp<0x156>(v); default: return dpp<0x157>(v);
+  }
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 // wave-uniform max via DPP inside the four 16-lane rows + readlane across them (no LDS round trips)
@@ -157,235 +170,76 @@ __device__ __forceinline__ float wave_max_fast(float v) {
   const float c = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), e = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
   return fmaxf(fmaxf(a, b), fmaxf(c, e));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+
+// wave-uniform sum, fixed order: DPP inside the 16-lane rows, then rows 0..3 left to right
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v = row16_sum(v);
+  const int vi = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), b = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), e = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return ((a + b) + c) + e;
 }
 
 constexpr int WB = RV_MAX_BEAM;
 constexpr int ATT_THREADS = 512;
+#define RV_STAMP(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 0 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
+constexpr float LOG2E = 1.4426950408889634f;
 
-// LDS carve-up of k_dec_attend (floats), shared with the host-side size computation
+// Static LDS shared by both attend kernels: output layer, new cell states, beam bookkeeping.
+struct AttShared {
+  float wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];   // W_fc [128][V] then b_fc [V]
+  float cnew[WB * RV_U];
+  float lprob[WB];
+  int fin[WB], len[WB], parent[WB];
+};
+
+// Dynamic LDS carve-up (floats), shared with the host-side size computation.
 struct AttLds {
-  int q, pq, sc, al, part, hcT, att, lg, total;
-  __host__ __device__ AttLds(int W, int TmP) {
+  int q, pq, sc, al, part, hcT, att, lg, fold, total;
+  __host__ __device__ AttLds(int W, int TmP, bool flash) {
     int o = 0;
     q = o; o += W * RV_U;
-    pq = o; o += W * RV_U;
-    sc = o; o += W * TmP;
-    al = o; o += TmP * WB;
-    part = o; o += 8 * W * RV_E;          // context partials [8][W][256]; reused as [4][W][128] by phase E
-    hcT = o; o += (RV_U + RV_E) * WB;     // [h ; context] k-major, beam-minor
+    pq = o; o += flash ? W * RV_E : W * RV_U;   // Bahdanau processed query [W][128] / flash q' [W][256]
+    sc = o; o += flash ? 32 * WB * 2 : W * TmP; // two-pass: scores [W][TmP]; flash: per-stream (max, sum) [32][WB][2]
+    al = o; o += flash ? 2 * WB : TmP * WB;     // two-pass: alignments [TmP][WB]; flash: merged (max, 1/sum)
+    part = o; o += 8 * W * RV_E;                // partial sums [8][W][256] (also [16][W][128], [4][W][128])
+    hcT = o; o += (RV_U + RV_E) * WB;           // [h ; context] k-major, beam-minor
     att = o; o += W * RV_U;
     lg = o; o += WB * RV_MAX_VOCAB;
+    fold = o; o += flash ? 8 * W * 4 * 32 * 4 : 0;   // flash: wave-private fold slabs [8][W*4][32] float4
     total = o;
   }
 };
 
-// TB / TD: compile-time trip counts of the score / context sweeps (T_m <= 32*TB and <= 8*TD), so every
-// load of a sweep is issued before its first use (the kernel is latency-bound, not bandwidth-bound).
-template <int W, int TB, int TD>
-__global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step) {
-  extern __shared__ __align__(16) float dsm[];
-  const int Tm = d.Tm, V = d.V;
-  const int TmP = (Tm + 3) & ~3;
-  const AttLds L(W, TmP);
-  float* q = dsm + L.q;        // [W][128]
-  float* pq = dsm + L.pq;      // [W][128]
-  float* sc = dsm + L.sc;      // [W][TmP]
-  float* al = dsm + L.al;      // [TmP][WB]
-  float* part = dsm + L.part;
-  float* hcT = dsm + L.hcT;    // [384][WB]
-  float* att = dsm + L.att;    // [W][128]
-  float* lg = dsm + L.lg;      // [WB][8]
-  __shared__ int s_parent[WB];
-  __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];   // W_fc [128][V] then b_fc [V]
-  __shared__ float s_cnew[WB * RV_U];
-  __shared__ float s_lprob[WB];
-  __shared__ int s_fin[WB], s_len[WB];
-
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (step > 0 && d.nfin[step - 1] >= d.B) {      // whole batch finished earlier: propagate
-    if (tid == 0) atomicAdd(&d.nfin[step], 1);
-    return;
-  }
-  const size_t row0 = (size_t)b * W;
-
-  // ---- streaming loads first: nothing below depends on them until phases B / D, and the kernel
-  //      is HBM-bound (keys + values = 1.5 KB per memory step per chunk), so the stream must start
-  //      at entry and run under the small phases.  Issue order = completion order (vmcnt is
-  //      in-order): keys (phase B) before values (phase D).
-  const int sub = tid & 15, grp = tid >> 4;       // B: a DPP row (16 lanes) shares one memory step
-  const int cg = tid & 63, tg = tid >> 6;         // D: thread = (4 columns, 1 of 8 interleaved t-groups)
-  constexpr int TD1c = W <= 5 ? 16 : 6;           // value rows in flight beside the keys (VGPR budget)
-  constexpr int TD1 = TD < TD1c ? TD : TD1c;
-  float4 k0[TB], k1[TB];
-  uint8_t mk[TB];
-  float4 vv[TD];
-  {
-    const float* kbase = d.keys + (size_t)b * Tm * RV_U + 8 * sub;
-    const uint8_t* mrow = d.mask + (size_t)b * Tm;
-#pragma unroll
-    for (int u = 0; u < TB; ++u) {
-      const int t = min(grp + 32 * u, Tm - 1);
-      const float4* kp = reinterpret_cast<const float4*>(kbase + (size_t)t * RV_U);
-      k0[u] = kp[0]; k1[u] = kp[1];
-      mk[u] = mrow[t];
-    }
-    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * cg;
-#pragma unroll
-    for (int u = 0; u < TD1; ++u) {
-      const int t = min(tg + 8 * u, Tm - 1);
-      vv[u] = *reinterpret_cast<const float4*>(vbase + (size_t)t * RV_E);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- A: one round of small loads: query = cell output h of every beam (also the first 128 rows
-  //         of hcT), the new cell states, the beam bookkeeping and the output layer -> LDS
+// ---- phase A: one round of small loads -> LDS: query = cell output h of every beam (also rows
+// 0..127 of hcT), the new cell states, the beam bookkeeping and the output layer.
+template <int W>
+__device__ __forceinline__ void att_prologue(const DecState& d, AttShared& S, float* q, float* hcT, size_t row0, int tid) {
+  const int V = d.V;
   for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
     const float v = d.h_new[row0 * RV_U + i];
     q[i] = v;
     hcT[(i & 127) * WB + (i >> 7)] = v;
-    s_cnew[i] = d.c_new[row0 * RV_U + i];
+    S.cnew[i] = d.c_new[row0 * RV_U + i];
   }
-  for (int i = tid; i < RV_U * V; i += ATT_THREADS) s_wfc[i] = d.W_fc[i];
-  if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
+  for (int i = tid; i < RV_U * V; i += ATT_THREADS) S.wfc[i] = d.W_fc[i];
+  if (tid < V) S.wfc[RV_U * V + tid] = d.b_fc[tid];
   if (tid < W) {
-    s_fin[tid] = d.finished[row0 + tid];
-    s_lprob[tid] = d.log_probs[row0 + tid];
-    s_len[tid] = d.lengths[row0 + tid];
+    S.fin[tid] = d.finished[row0 + tid];
+    S.lprob[tid] = d.log_probs[row0 + tid];
+    S.len[tid] = d.lengths[row0 + tid];
   }
-  __syncthreads();
-  if (d.dbg_stop == 1) return;
-  if (d.attention == 1) {   // Bahdanau: processed query = q . W_q ; thread = (column, K quarter)
-    const int jj = tid & 127, kq = tid >> 7;
-    float acc[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) acc[w] = 0.f;
-    for (int k = kq * 32; k < kq * 32 + 32; ++k) {
-      const float wq = d.W_q[k * RV_U + jj];
-#pragma unroll
-      for (int w = 0; w < W; ++w) acc[w] = fmaf(q[w * RV_U + k], wq, acc[w]);
-    }
-#pragma unroll
-    for (int w = 0; w < W; ++w) part[(kq * W + w) * RV_U + jj] = acc[w];
-    __syncthreads();
-    if (tid < RV_U)
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-        pq[w * RV_U + tid] = (part[(0 * W + w) * RV_U + tid] + part[(1 * W + w) * RV_U + tid]) +
-                             (part[(2 * W + w) * RV_U + tid] + part[(3 * W + w) * RV_U + tid]);
-    __syncthreads();
-  }
+}
 
-  // ---- B: scores from the keys already in registers
-  {
-    float qr[W][8], vr[8];
-    const float* qsrc = d.attention == 1 ? pq : q;
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) qr[w][i] = qsrc[w * RV_U + 8 * sub + i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vr[i] = d.attention == 1 ? d.v_att[8 * sub + i] : 0.f;
-#pragma unroll
-    for (int u = 0; u < TB; ++u) {
-      const int t = grp + 32 * u;
-      const float kk[8] = {k0[u].x, k0[u].y, k0[u].z, k0[u].w, k1[u].x, k1[u].y, k1[u].z, k1[u].w};
-      float mine = 0.f;
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        float p = 0.f;
-        if (d.attention == 1) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) p = fmaf(vr[i], tanhf(kk[i] + qr[w][i]), p);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) p = fmaf(kk[i], qr[w][i], p);
-        }
-        p = row16_sum(p);
-        mine = sub == w ? p : mine;
-      }
-      if (t < Tm && sub < W) sc[sub * TmP + t] = mk[u] ? mine : -INFINITY;   // _maybe_mask_score
-    }
-  }
-  if (d.dbg_stop == 2) return;
-  // ---- D (loads, second part): the rest of the value rows, now that the key registers are free
-  if (TD > TD1) {
-    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * cg;
-#pragma unroll
-    for (int u = TD1; u < TD; ++u) {
-      const int t = min(tg + 8 * u, Tm - 1);
-      vv[u] = *reinterpret_cast<const float4*>(vbase + (size_t)t * RV_E);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-
-  // ---- C: softmax over T_m, one wave per beam
-  {
-    const int lane = tid & 63, wv = tid >> 6;
-    if (wv < W) {
-      const int w = wv;
-      float m = -INFINITY;
-      for (int t = lane; t < Tm; t += 64) m = fmaxf(m, sc[w * TmP + t]);
-      m = wave_max(m);
-      float sum = 0.f;
-      for (int t = lane; t < Tm; t += 64) {
-        const float e = expf(sc[w * TmP + t] - m);
-        sc[w * TmP + t] = e;
-        sum += e;
-      }
-      sum = wave_sum(sum);
-      for (int t = lane; t < Tm; t += 64) {
-        const float a = sc[w * TmP + t] / sum;
-        al[t * WB + w] = a;
-        if (d.step_align) d.step_align[(((size_t)step * d.B + b) * W + w) * Tm + t] = a;
-      }
-    }
-  }
-  __syncthreads();
-
-  if (d.dbg_stop == 3) return;
-  // ---- D (math): context = sum_t alpha_t * values_t
-  {
-    f2 acc[W][2];
-#pragma unroll
-    for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-#pragma unroll
-    for (int u = 0; u < TD; ++u) {
-      const int t = tg + 8 * u;
-      if (t < Tm) {
-        float a[WB];
-        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(&al[t * WB]);
-        if (W > 4) *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(&al[t * WB + 4]);
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-          acc[w][0] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].x, vv[u].y}, acc[w][0]);
-          acc[w][1] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].z, vv[u].w}, acc[w][1]);
-        }
-      }
-    }
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-      *reinterpret_cast<float4*>(&part[((tg * W + w) * RV_E) + 4 * cg]) =
-          make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
-  }
-  __syncthreads();
-  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction of the 8 partials
-    const int w = i >> 8, col = i & 255;
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) s += part[(g * W + w) * RV_E + col];
-    hcT[(RV_U + col) * WB + w] = s;
-  }
-  __syncthreads();
-
-  if (d.dbg_stop == 4) return;
-  // ---- E: attention = [h ; context] . W_att   (Dense, no bias, no activation)
-  //         thread = (4 output columns, 1 of 16 K-groups of 24 rows); 24 float4 weight loads in flight
+// ---- phases E-H: attention layer, output layer, sampler / beam step, parent-gather of the state.
+// Expects hcT = [h ; context] complete and a barrier behind it.
+template <int W>
+__device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const float* q, const float* hcT, float* part,
+                                         float* att, float* lg, int b, int step, int tid) {
+  const int V = d.V;
+  const size_t row0 = (size_t)b * W;
+  // E: attention = [h ; context] . W_att   (Dense, no bias, no activation)
+  //    thread = (4 output columns, 1 of 16 K-groups of 24 rows); 24 float4 weight loads in flight
   {
     const int d4 = tid & 31, kg = tid >> 5;
     float4 wv[24];
@@ -421,17 +275,18 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
     att[i] = s0;
   }
   __syncthreads();
-
+  RV_STAMP(d, step, 5);
   if (d.dbg_stop == 5) return;
-  // ---- F: logits = attention . W_fc + b_fc ; one 16-lane row per (beam, token)
+
+  // F: logits = attention . W_fc + b_fc ; one 16-lane row per (beam, token)
   {
-    const int sub = tid & 15, o = tid >> 4;         // o < 32 outputs per pass
+    const int sub = tid & 15, o = tid >> 4;         // 32 outputs per pass
     for (int ob = o; ob < W * V; ob += ATT_THREADS / 16) {
       const int w = ob / V, v = ob % V;
       float p = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) p = fmaf(att[w * RV_U + 8 * sub + i], s_wfc[(8 * sub + i) * V + v], p);
-      p = row16_sum(p) + s_wfc[RV_U * V + v];
+      for (int i = 0; i < 8; ++i) p = fmaf(att[w * RV_U + 8 * sub + i], S.wfc[(8 * sub + i) * V + v], p);
+      p = row16_sum(p) + S.wfc[RV_U * V + v];
       if (sub == 0) {
         lg[w * RV_MAX_VOCAB + v] = p;
         if (d.step_logits) d.step_logits[(((size_t)step * d.B + b) * W + w) * V + v] = p;
@@ -439,9 +294,10 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
     }
   }
   __syncthreads();
-
+  RV_STAMP(d, step, 6);
   if (d.dbg_stop == 6) return;
-  // ---- G: sampler / beam step, wave 0: lane = candidate (beam w, token v), W*V <= 64
+
+  // G: sampler / beam step, wave 0: lane = candidate (beam w, token v), W*V <= 64
   if (tid < 64) {
     const int lane = tid, w = lane / V, v = lane % V;
     const bool cand = lane < W * V;
@@ -453,11 +309,11 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
       float m = lg[w * RV_MAX_VOCAB];
       for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
       float ssum = 0.f;
-      for (int x = 0; x < V; ++x) ssum += expf(lg[w * RV_MAX_VOCAB + x] - m);
-      const float lse = logf(ssum);
-      const bool fin = s_fin[w] != 0;
+      for (int x = 0; x < V; ++x) ssum += __expf(lg[w * RV_MAX_VOCAB + x] - m);
+      const float lse = __logf(ssum);
+      const bool fin = S.fin[w] != 0;
       const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (lg[w * RV_MAX_VOCAB + v] - m) - lse;
-      val = s_lprob[w] + lp;
+      val = S.lprob[w] + lp;
     }
     // top-W by repeated wave max; ties -> lowest flat index (tf.math.top_k order)
     bool taken = !cand;
@@ -473,33 +329,427 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
     bool nf = false; int nl = 0;
     if (lane < W) {
       if (d.greedy) {
-        nf = s_fin[0] != 0 || my_word == d.end_token;
+        nf = S.fin[0] != 0 || my_word == d.end_token;
       } else {
-        const bool pf = s_fin[my_par] != 0;
+        const bool pf = S.fin[my_par] != 0;
         nf = pf || my_word == d.end_token;
-        nl = s_len[my_par] + (pf ? 0 : 1);
+        nl = S.len[my_par] + (pf ? 0 : 1);
       }
     }
     const unsigned long long fmask = __ballot(lane < W && nf);
-    if (lane < W) {   // all reads of the old beam state happened above (same wave, program order)
+    if (lane < W) {
       d.step_ids[o + lane] = my_word; d.parent_ids[o + lane] = my_par; d.step_scores[o + lane] = my_val;
       d.tok[row0 + lane] = my_word;
       d.finished[row0 + lane] = nf;
       if (!d.greedy) { d.log_probs[row0 + lane] = my_val; d.lengths[row0 + lane] = nl; }
-      s_parent[lane] = my_par;
+      S.parent[lane] = my_par;
     }
     if (lane == 0 && __popcll(fmask) == W) atomicAdd(&d.nfin[step], 1);
   }
   __syncthreads();
-
+  RV_STAMP(d, step, 7);
   if (d.dbg_stop == 7) return;
-  // ---- H: next-step state, gathered by parent beam: xh = [attention | h], c
+
+  // H: next-step state, gathered by parent beam: xh = [attention | h], c
   for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
-    const int w = i >> 7, e = i & 127, p = s_parent[w];
+    const int w = i >> 7, e = i & 127, p = S.parent[w];
     d.xh[(row0 + w) * RV_E + e] = att[p * RV_U + e];
     d.xh[(row0 + w) * RV_E + RV_U + e] = q[p * RV_U + e];
-    d.c[(row0 + w) * RV_U + e] = s_cnew[p * RV_U + e];
+    d.c[(row0 + w) * RV_U + e] = S.cnew[p * RV_U + e];
   }
+}
+
+// =====================================================================================
+// Two-pass attend (exact reference dataflow: scores from keys, then context from values).
+// Used for Bahdanau attention and whenever per-step alignments are tapped.
+// TB / TD: compile-time trip counts of the score / context sweeps (T_m <= 32*TB and <= 8*TD), so every
+// load of a sweep is issued before its first use.
+template <int W, int TB, int TD>
+__global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step) {
+  extern __shared__ __align__(16) float dsm[];
+  const int Tm = d.Tm;
+  const int TmP = (Tm + 3) & ~3;
+  const AttLds L(W, TmP, false);
+  float* q = dsm + L.q;        // [W][128]
+  float* pq = dsm + L.pq;      // [W][128]
+  float* sc = dsm + L.sc;      // [W][TmP]
+  float* al = dsm + L.al;      // [TmP][WB]
+  float* part = dsm + L.part;
+  float* hcT = dsm + L.hcT;    // [384][WB]
+  float* att = dsm + L.att;    // [W][128]
+  float* lg = dsm + L.lg;      // [WB][8]
+  __shared__ AttShared S;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (step > 0 && d.nfin[step - 1] >= d.B) {      // whole batch finished earlier: propagate
+    if (tid == 0) atomicAdd(&d.nfin[step], 1);
+    return;
+  }
+  const size_t row0 = (size_t)b * W;
+  att_prologue<W>(d, S, q, hcT, row0, tid);
+  __syncthreads();
+  if (d.attention == 1) {   // Bahdanau: processed query = q . W_q ; thread = (column, K quarter)
+    const int jj = tid & 127, kq = tid >> 7;
+    float acc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) acc[w] = 0.f;
+    for (int k = kq * 32; k < kq * 32 + 32; ++k) {
+      const float wq = d.W_q[k * RV_U + jj];
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc[w] = fmaf(q[w * RV_U + k], wq, acc[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) part[(kq * W + w) * RV_U + jj] = acc[w];
+    __syncthreads();
+    if (tid < RV_U)
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        pq[w * RV_U + tid] = (part[(0 * W + w) * RV_U + tid] + part[(1 * W + w) * RV_U + tid]) +
+                             (part[(2 * W + w) * RV_U + tid] + part[(3 * W + w) * RV_U + tid]);
+    __syncthreads();
+  }
+
+  // ---- B: scores.  A DPP row (16 lanes) shares one memory step; all key loads in flight first.
+  {
+    const int sub = tid & 15, grp = tid >> 4;
+    float qr[W][8], vr[8];
+    const float* qsrc = d.attention == 1 ? pq : q;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qr[w][i] = qsrc[w * RV_U + 8 * sub + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vr[i] = d.attention == 1 ? d.v_att[8 * sub + i] : 0.f;
+    const float* kbase = d.keys + (size_t)b * Tm * RV_U + 8 * sub;
+    const uint8_t* mrow = d.mask + (size_t)b * Tm;
+    float4 k0[TB], k1[TB];
+    uint8_t mk[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int t = min(grp + 32 * u, Tm - 1);
+      const float4* kp = reinterpret_cast<const float4*>(kbase + (size_t)t * RV_U);
+      k0[u] = kp[0]; k1[u] = kp[1];
+      mk[u] = mrow[t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int t = grp + 32 * u;
+      const float kk[8] = {k0[u].x, k0[u].y, k0[u].z, k0[u].w, k1[u].x, k1[u].y, k1[u].z, k1[u].w};
+      float mine = 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        float p = 0.f;
+        if (d.attention == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) p = fmaf(vr[i], tanhf(kk[i] + qr[w][i]), p);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) p = fmaf(kk[i], qr[w][i], p);
+        }
+        p = row16_sum(p);
+        mine = sub == w ? p : mine;
+      }
+      if (t < Tm && sub < W) sc[sub * TmP + t] = mk[u] ? mine : -INFINITY;   // _maybe_mask_score
+    }
+  }
+
+  // ---- D (loads): every value row this thread needs, issued before the softmax so the memory
+  //         latency hides under phase C.  thread = (4 columns, 1 of 8 interleaved t-groups)
+  const int cg = tid & 63, tg = tid >> 6;
+  float4 vv[TD];
+  {
+    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * cg;
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+      const int t = min(tg + 8 * u, Tm - 1);
+      vv[u] = *reinterpret_cast<const float4*>(vbase + (size_t)t * RV_E);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+
+  // ---- C: softmax over T_m, one wave per beam
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    if (wv < W) {
+      const int w = wv;
+      float m = -INFINITY;
+      for (int t = lane; t < Tm; t += 64) m = fmaxf(m, sc[w * TmP + t]);
+      m = wave_max(m);
+      float sum = 0.f;
+      for (int t = lane; t < Tm; t += 64) {
+        const float e = expf(sc[w * TmP + t] - m);
+        sc[w * TmP + t] = e;
+        sum += e;
+      }
+      sum = wave_sum(sum);
+      for (int t = lane; t < Tm; t += 64) {
+        const float a = sc[w * TmP + t] / sum;
+        al[t * WB + w] = a;
+        if (d.step_align) d.step_align[(((size_t)step * d.B + b) * W + w) * Tm + t] = a;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- D (math): context = sum_t alpha_t * values_t
+  {
+    f2 acc[W][2];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+      const int t = tg + 8 * u;
+      if (t < Tm) {
+        float a[WB];
+        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(&al[t * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(&al[t * WB + 4]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].x, vv[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{a[w], a[w]}, f2{vv[u].z, vv[u].w}, acc[w][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      *reinterpret_cast<float4*>(&part[((tg * W + w) * RV_E) + 4 * cg]) =
+          make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+  }
+  __syncthreads();
+  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction of the 8 partials
+    const int w = i >> 8, col = i & 255;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[(g * W + w) * RV_E + col];
+    hcT[(RV_U + col) * WB + w] = s;
+  }
+  __syncthreads();
+  att_tail<W>(d, S, q, hcT, part, att, lg, b, step, tid);
+}
+
+// =====================================================================================
+// Single-pass ("flash") attend for Luong attention -- the production path.
+// The per-step attention is HBM-bound: keys [T_m,128] + values [T_m,256] per chunk are re-read every
+// step (130 MB per step at B = 256).  Luong's score is linear in the keys, and keys = values . W_mem,
+// so   score_t = q . (values_t . W_mem) = values_t . q'   with  q' = W_mem . q   (256-vector).
+// One sweep over `values` then yields scores AND context (online softmax), and `keys` is never read:
+// a third fewer bytes.  fp32 re-association only (|delta score| ~ 1e-6; tolerance 1e-4).
+// 32 independent streams per chunk (a DPP row of 16 lanes each, 16 columns per lane) walk
+// t = stream, stream+32, ... with a 3-deep register prefetch, keep their own running
+// (max, sum, context[W][256]) and are merged once at the end in a fixed order.
+// q' carries log2(e) so the exponentials are bare v_exp_f32.
+template <int W>
+__global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, const float* __restrict__ WmemT, int step) {
+  extern __shared__ __align__(16) float dsm[];
+  const int Tm = d.Tm;
+  const AttLds L(W, 0, true);
+  float* q = dsm + L.q;        // [W][128]
+  float* qp = dsm + L.pq;      // [W][256]  q' * log2(e)
+  float* ml = dsm + L.sc;      // [32][WB][2] per-stream (max, sum)
+  float* mg = dsm + L.al;      // [WB][2] merged (max, 1/sum)
+  float* part = dsm + L.part;  // [8][W][256]
+  float* hcT = dsm + L.hcT;    // [384][WB]
+  float* att = dsm + L.att;    // [W][128]
+  float* lg = dsm + L.lg;      // [WB][8]
+  float* fold = dsm + L.fold;
+  __shared__ AttShared S;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (step > 0 && d.nfin[step - 1] >= d.B) {
+    if (tid == 0) atomicAdd(&d.nfin[step], 1);
+    return;
+  }
+  const size_t row0 = (size_t)b * W;
+  RV_STAMP(d, step, 0);
+  const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4;   // sid: stream 0..31
+  constexpr int PD = 3;                                                       // prefetch depth (iterations)
+  const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * sub;
+  const uint8_t* mrow = d.mask + (size_t)b * Tm;
+  const int nit = (Tm + 31) >> 5;
+  float4 pv[PD][4];
+  uint8_t pm[PD];
+  auto issue = [&](int slot, int it) {
+    const int t = min(sid + 32 * it, Tm - 1);
+    const float* p = vbase + (size_t)t * RV_E;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pv[slot][m] = *reinterpret_cast<const float4*>(p + 64 * m);
+    pm[slot] = mrow[t];
+  };
+  att_prologue<W>(d, S, q, hcT, row0, tid);            // small loads first: vmcnt retires in issue order
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < PD; ++k) issue(k, k);            // the stream starts before any math
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  RV_STAMP(d, step, 1);
+  // q' = W_mem . q (times log2 e): thread = (4 columns, 1 of 8 j-groups of 16), W_memT is [128][256]
+  {
+    const int c4 = tid & 63, jg = tid >> 6;
+    float4 wm[16];
+    const float* wp = WmemT + (size_t)(16 * jg) * RV_E + 4 * c4;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
+    f2 acc[W][2];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      float hv[WB];
+      *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + u) * WB]);
+      if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + u) * WB + 4]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].x, wm[u].y}, acc[w][0]);
+        acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      *reinterpret_cast<float4*>(&part[(jg * W + w) * RV_E + 4 * c4]) =
+          make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+  }
+  __syncthreads();
+  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {
+    const int w = i >> 8, col = i & 255;
+    float s0 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+    qp[i] = s0 * LOG2E;
+  }
+  __syncthreads();
+
+  RV_STAMP(d, step, 2);
+  // ---- the sweep.  Lane (sub) owns columns {4 sub + 64 m + 0..3 : m = 0..3} of its stream's rows.
+  // Beam w's running (max, sum) of a stream lives in lane sub == w of its row; the rescale factor and
+  // the new weight reach the other lanes through DPP row_newbcast.
+  float M = -INFINITY, l = 0.f;
+  f2 acc[W][8];
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[w][i] = f2{0.f, 0.f};
+  for (int it0 = 0; it0 < nit; it0 += PD) {
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+      const int it = it0 + k;
+      if (it < nit) {                                   // wave-uniform
+        asm volatile("" ::: "memory");                  // keep the q' LDS reads inside the loop (LICM would
+                                                        // pin 16*W registers and spill; spill traffic drains vmcnt)
+        const int t = sid + 32 * it;
+        const bool live = t < Tm && pm[k] != 0;
+        f2 v[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { v[2 * m] = f2{pv[k][m].x, pv[k][m].y}; v[2 * m + 1] = f2{pv[k][m].z, pv[k][m].w}; }
+        if (it + PD < nit) issue(k, it + PD);           // refill this slot (registers already copied)
+        float mys = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          f2 pp = f2{0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float4 qv = *reinterpret_cast<const float4*>(&qp[w * RV_E + 4 * sub + 64 * m]);
+            pp = __builtin_elementwise_fma(v[2 * m], f2{qv.x, qv.y}, pp);
+            pp = __builtin_elementwise_fma(v[2 * m + 1], f2{qv.z, qv.w}, pp);
+          }
+          const float sw = row16_sum(pp.x + pp.y);      // log2-domain score, uniform across the row
+          mys = sub == w ? sw : mys;
+        }
+        if (d.step_align && sub < W && t < Tm)          // tap: raw masked score (host normalises)
+          d.step_align[(((size_t)step * d.B + b) * W + sub) * Tm + t] = live ? mys : -INFINITY;
+        mys = live ? mys : -INFINITY;                   // _maybe_mask_score
+        const float Mn = fmaxf(M, mys);
+        const float mref = Mn == -INFINITY ? 0.f : Mn;
+        const float scl = exp2f(M - mref), pe = exp2f(mys - mref);
+        l = fmaf(l, scl, pe);
+        M = Mn;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const float sc_w = row_bcast(scl, w), pe_w = row_bcast(pe, w);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            acc[w][i] = __builtin_elementwise_fma(acc[w][i], f2{sc_w, sc_w}, f2{pe_w, pe_w} * v[i]);
+        }
+      }
+    }
+  }
+  RV_STAMP(d, step, 3);
+  // ---- merge the 32 streams: global max / sum per beam, then a fixed-order sum of rescaled contexts
+  if (sub < W) { ml[(sid * WB + sub) * 2] = M; ml[(sid * WB + sub) * 2 + 1] = l; }
+  __syncthreads();
+  if (wv < W) {                          // wave w merges beam w: lane = stream
+    const float Ms = lane < 32 ? ml[(lane * WB + wv) * 2] : -INFINITY;
+    const float ls = lane < 32 ? ml[(lane * WB + wv) * 2 + 1] : 0.f;
+    const float Mg = wave_max_fast(Ms);
+    const float lsum = wave_sum_fast(Ms == -INFINITY ? 0.f : ls * exp2f(Ms - Mg));
+    if (lane == 0) {
+      mg[wv * 2] = Mg;
+      mg[wv * 2 + 1] = 1.0f / lsum;      // all-masked chunk: 1/0 -> inf, context NaN like the reference's softmax
+    }
+  }
+  __syncthreads();
+  {
+    const float Mg = sub < W ? mg[sub * 2] : 0.f;
+    const float fs = M == -INFINITY ? 0.f : exp2f(M - Mg);          // this stream's weight for beam `sub`
+    // fold the wave's 4 streams (rows hold the same columns) through a wave-private LDS slab:
+    // rows 2,3 -> rows 0,1, then row 1 -> row 0.  Same-wave exchange: no workgroup barrier.
+    float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (W * 4 * 32 * 4));
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const float f = row_bcast(fs, w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[w][i] = acc[w][i] * f2{f, f};
+    }
+    if (lane >= 32) {
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          slab[(w * 4 + m) * 32 + (lane - 32)] = make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the wave's LDS writes have landed
+    if (lane < 32) {
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float4 o = slab[(w * 4 + m) * 32 + lane];
+          acc[w][2 * m] += f2{o.x, o.y}; acc[w][2 * m + 1] += f2{o.z, o.w};
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (lane >= 16 && lane < 32) {
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          slab[(w * 4 + m) * 32 + (lane - 16)] = make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (lane < 16) {
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float4 o = slab[(w * 4 + m) * 32 + lane];
+          *reinterpret_cast<float4*>(&part[(wv * W + w) * RV_E + 4 * sub + 64 * m]) =
+              make_float4(acc[w][2 * m].x + o.x, acc[w][2 * m].y + o.y, acc[w][2 * m + 1].x + o.z, acc[w][2 * m + 1].y + o.w);
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction over the 8 waves
+    const int w = i >> 8, col = i & 255;
+    float s0 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+    hcT[(RV_U + col) * WB + w] = s0 * mg[w * 2 + 1];
+  }
+  __syncthreads();
+  RV_STAMP(d, step, 4);
+  att_tail<W>(d, S, q, hcT, part, att, lg, b, step, tid);
+  RV_STAMP(d, step, 8);
 }
 
 // One 64-thread workgroup per chunk: the chunk's [S,W] ids/parents are staged in LDS so the
@@ -584,30 +834,40 @@ void launch_dec_cell(const DecState& d, const float* WcatT, const float* Wtok, c
 template <int W, int TB, int TD>
 static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {
   const int TmP = (d.Tm + 3) & ~3;
-  const size_t shm = sizeof(float) * AttLds(W, TmP).total;
-  static size_t configured = 64 * 1024;
-  if (shm > configured) {   // > 64 KB of dynamic LDS needs the opt-in
+  const size_t shm = sizeof(float) * AttLds(W, TmP, false).total;
+  static size_t configured = 48 * 1024;
+  if (shm > configured) {   // large dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend<W, TB, TD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     configured = shm;
   }
   hipLaunchKernelGGL((k_dec_attend<W, TB, TD>), dim3(d.B), dim3(ATT_THREADS), shm, s, d, step);
 }
 template <int W>
-static void launch_attend_w(const DecState& d, int step, hipStream_t s) {
+static void launch_attend_w(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s) {
+  if (flash) {
+    const size_t shm = sizeof(float) * AttLds(W, 0, true).total;
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      configured = true;
+    }
+    hipLaunchKernelGGL((k_dec_attend_flash<W>), dim3(d.B), dim3(ATT_THREADS), shm, s, d, WmemT, step);
+    return;
+  }
   if (d.Tm <= 64) launch_attend_wt<W, 2, 8>(d, step, s);
   else if (d.Tm <= 224) launch_attend_wt<W, 7, 28>(d, step, s);
   else launch_attend_wt<W, 11, 44>(d, step, s);
 }
-void launch_dec_attend(const DecState& d, int step, hipStream_t s) {
+void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s) {
   switch (d.W) {
-    case 1: launch_attend_w<1>(d, step, s); break;
-    case 2: launch_attend_w<2>(d, step, s); break;
-    case 3: launch_attend_w<3>(d, step, s); break;
-    case 4: launch_attend_w<4>(d, step, s); break;
-    case 5: launch_attend_w<5>(d, step, s); break;
-    case 6: launch_attend_w<6>(d, step, s); break;
-    case 7: launch_attend_w<7>(d, step, s); break;
-    default: launch_attend_w<8>(d, step, s); break;
+    case 1: launch_attend_w<1>(d, WmemT, flash, step, s); break;
+    case 2: launch_attend_w<2>(d, WmemT, flash, step, s); break;
+    case 3: launch_attend_w<3>(d, WmemT, flash, step, s); break;
+    case 4: launch_attend_w<4>(d, WmemT, flash, step, s); break;
+    case 5: launch_attend_w<5>(d, WmemT, flash, step, s); break;
+    case 6: launch_attend_w<6>(d, WmemT, flash, step, s); break;
+    case 7: launch_attend_w<7>(d, WmemT, flash, step, s); break;
+    default: launch_attend_w<8>(d, WmemT, flash, step, s); break;
   }
 }
 void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s) {

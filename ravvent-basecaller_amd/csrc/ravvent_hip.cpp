@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -43,6 +44,9 @@ struct RvContext {
   bool loaded = false;
   std::vector<std::vector<LstmW>> enc[2];   // [enc][layer][dir]
   LstmW dec{};
+  float* d_WmemT = nullptr;                 // derived: W_mem^T [128][256]
+  int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
+  int lflash = 0;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
@@ -224,13 +228,14 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
 
 void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool profiled) {
   const float* Wcat = h->d_WcatT;
+  const bool flash = h->lflash != 0;
   for (int step = 0; step < d.L - 1; ++step) {
     if (profiled) {
       { Scope sc(h, "dec_cell"); launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s); }
-      { Scope sc(h, "dec_attend"); launch_dec_attend(d, step, s); }
+      { Scope sc(h, "dec_attend"); launch_dec_attend(d, h->d_WmemT, flash, step, s); }
     } else {
       launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s);
-      launch_dec_attend(d, step, s);
+      launch_dec_attend(d, h->d_WmemT, flash, step, s);
     }
   }
 }
@@ -287,6 +292,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   d.keys = h->keys; d.values = h->enc_out; d.mask = h->mask;
   d.W_att = h->W_att; d.W_fc = h->W_fc; d.b_fc = h->b_fc; d.W_q = h->W_q; d.v_att = h->v_att;
   const int N = B * d.W;
+  h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && d.W <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
   if (h->opt_taps) {
     const size_t need = (size_t)steps * N * Tm;
     if (need > h->step_align_cap) {
@@ -307,7 +313,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   launch_dec_init(d, s);
 
   if (h->opt_graph && h->opt_profile != 2) {
-    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps};
+    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -386,6 +392,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)RV_G * RV_E));
+  TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
   TRY(dalloc(h, &h->d_raw, B * Tr));
   TRY(dalloc(h, &h->d_ev, B * Te * 5));
@@ -401,7 +408,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
   TRY(dalloc(h, &h->keys, B * Tm * RV_U));
   DecState& d = h->dec_st;
-  if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);   // timing ablation only; results are invalid when set
+  if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
+  if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
   TRY(dalloc(h, &d.xh, N * RV_E));
   TRY(dalloc(h, &d.z, N * RV_G));
   TRY(dalloc(h, &d.c, N * RV_U));
@@ -453,6 +461,11 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
     for (int k = 0; k < RV_E; ++k)
       for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
     HIPCHK(h, hipMemcpy(h->d_WcatT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
+    std::vector<float> m((size_t)RV_U * RV_E);
+    for (int i = 0; i < RV_E; ++i)
+      for (int j = 0; j < RV_U; ++j) m[(size_t)j * RV_E + i] = blob[moff + (size_t)i * RV_U + j];
+    HIPCHK(h, hipMemcpy(h->d_WmemT, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->loaded = true;
@@ -480,6 +493,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!h || !key) return RV_EINVAL;
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
+  else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
   else if (!strcmp(key, "profile")) h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value);
   else return fail(h, RV_EINVAL, "unknown option '%s'", key);
   return RV_OK;
@@ -493,6 +507,15 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
   if (!strcmp(name, "enc_output")) { src = h->enc_out; n = B * Tm * RV_E; }
   else if (!strcmp(name, "mask")) { src = h->mask; n = B * Tm; kind = 2; }
   else if (!strcmp(name, "keys")) { src = h->keys; n = B * Tm * RV_U; }
+  else if (!strcmp(name, "dbg_stamps")) {
+    if (!d.dbg_ts) return fail(h, RV_ESTATE, "set RV_DBG_STAMPS=1 before rv_create");
+    long long ts[16];
+    HIPCHK(h, hipMemcpy(ts, d.dbg_ts, sizeof ts, hipMemcpyDeviceToHost));
+    *n_written = 16;
+    if (!dst || dst_floats < 16) return fail(h, RV_EINVAL, "dbg_stamps needs 16 floats");
+    for (int i = 0; i < 16; ++i) dst[i] = (float)(ts[i] - ts[0]);
+    return RV_OK;
+  }
   else if (!strcmp(name, "step_ids")) { src = d.step_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "parent_ids")) { src = d.parent_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "step_scores")) { src = d.step_scores; n = S * B * W; }
@@ -509,6 +532,16 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (kind == 0) {
     HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (!strcmp(name, "step_alignments") && h->lflash) {
+      // the single-pass kernel taps raw log2-domain masked scores; normalise here (debug path only)
+      for (size_t r = 0; r < n / Tm; ++r) {
+        float* a = dst + r * Tm;
+        double mx = -INFINITY, sum = 0;
+        for (size_t t = 0; t < Tm; ++t) mx = std::max(mx, (double)a[t]);
+        for (size_t t = 0; t < Tm; ++t) sum += std::exp2((double)a[t] - mx);
+        for (size_t t = 0; t < Tm; ++t) a[t] = (float)(std::exp2((double)a[t] - mx) / sum);
+      }
+    }
   } else if (kind == 1) {
     std::vector<int32_t> tmp(n);
     HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -1,0 +1,62 @@
+"""Speed harness counterpart of `RavventPerformanceEvaluator.run`
+(/root/reference/ravvent_performance_evaluator.py:24-87): same call sequence -- slabs of
+`chunk_size` chunks -> `beam_search_prediction(beam_width=5)` -> per-base probabilities and
+strings -- and the same result-dict keys and phase timers.  The reference file itself imports
+TensorFlow and Biopython and cannot run here; read-level merging
+(`merger.py`) is a host-side "next" row and is reported as `t_merge = 0` with the per-chunk
+calls returned un-merged.
+"""
+from __future__ import annotations
+
+from timeit import default_timer as timer
+
+import numpy as np
+
+from . import utils
+
+
+class PerformanceEvaluator:
+    def __init__(self, basecaller, stride: int = 6):
+        self.basecaller = basecaller
+        self.stride = stride           # ravvent_performance_evaluator.py:16
+
+    @staticmethod
+    def _split_into_chunks(arr, def_chunk_size):
+        """ravvent_performance_evaluator.py:19-22"""
+        return np.array_split(arr, np.arange(1, arr.shape[0] // def_chunk_size + 1) * def_chunk_size)
+
+    def run_slabs(self, raw_snippets, event_snippets, nuc_tk_snippets, bases_num=None, samples_num=None,
+                  chunk_size: int = 1024, beam_width: int = 5):
+        """The body of `run()` after data loading: inputs are the padded snippet arrays
+        `load_data_from_single_signal_label` would return (data_loader.py:113-126)."""
+        start = timer()
+        data_chunks = list(zip(self._split_into_chunks(raw_snippets, chunk_size),
+                               self._split_into_chunks(event_snippets, chunk_size),
+                               self._split_into_chunks(nuc_tk_snippets, chunk_size)))
+        data_chunks = [d for d in data_chunks if d[0].shape[0] > 0]
+        t_data_loading = timer() - start
+        nuc_preds = []
+        t_predicting = t_postprocessing = 0.0
+        for data in data_chunks:
+            start = timer()
+            input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
+            pred_tokens, beam_scores = self.basecaller.beam_search_prediction(
+                input_data, beam_width=beam_width, max_output_len=target_data.shape[1])
+            t_predicting += timer() - start
+            start = timer()
+            scores = utils.calc_prob_logits_beam_search_scores(beam_scores).numpy()
+            seqs = self.basecaller.tokens_to_nuc_sequences(pred_tokens)
+            nuc_preds.extend((seq, list(sc[:len(seq)])) for seq, sc in zip(seqs, scores))
+            t_postprocessing += timer() - start
+        t_merge = 0.0
+        n_chunks = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
+        if bases_num is None:
+            bases_num = n_chunks * self.stride
+        return {
+            "bases_num": int(bases_num), "samples_num": samples_num, "chunks_num": n_chunks,
+            "t_data_loading": t_data_loading, "t_predicting": t_predicting,
+            "t_postprocessing": t_postprocessing, "t_merge": t_merge,
+            "total": t_data_loading + t_predicting + t_postprocessing + t_merge,
+            "total_processing": t_predicting + t_postprocessing + t_merge,
+            "nuc_preds": nuc_preds,
+        }

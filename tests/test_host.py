@@ -1,0 +1,116 @@
+"""CPU tests of the host logic: weight blob layout, config mirror, tokenizer / chunk format,
+evaluator slab splitting, shard ranges, and the C-ABI library's exported surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_weight_inventory_matches_survey(rv):
+    cfg = rv.RvConfig()
+    # 1,276,807 parameters for (128,128,enc 2,dec 1) + Bahdanau's W_q (16,384) + v (128)
+    assert rv.weights.blob_size(cfg) == 1_276_807 + 16_384 + 128
+    flat = rv.weights.init_weights(cfg, seed=1)
+    blob = rv.weights.pack(cfg, flat)
+    back = rv.weights.unpack(cfg, blob)
+    assert all((back[k] == flat[k]).all() for k in flat)
+    b = flat["enc_raw.0.fwd.b"]
+    assert (b[128:256] == 1).all() and b[:128].sum() == 0 and b[256:].sum() == 0      # unit_forget_bias
+    U = flat["enc_raw.0.fwd.U"].astype(np.float64)
+    assert np.abs(U.T @ U - np.eye(512))[:128, :128].max() < 1.0                      # sane scale
+    with pytest.raises(ValueError):
+        rv.weights.unpack(cfg, blob[:-1])
+
+
+def test_hash_init_is_exactly_reproducible(rv):
+    cfg = rv.RvConfig()
+    a = rv.weights.pack(cfg, rv.weights.init_weights(cfg, seed=7, scheme="hash"))
+    b = rv.weights.pack(cfg, rv.weights.init_weights(cfg, seed=7, scheme="hash"))
+    assert (a == b).all() and abs(float(a[:1000].astype(np.float64).sum()) - float(b[:1000].astype(np.float64).sum())) == 0
+    u = rv.weights._splitmix_uniform(5, 4)
+    assert np.allclose(u, rv.weights._splitmix_uniform(5, 4)) and (np.abs(u) <= 1).all()
+
+
+def test_weight_file_roundtrip(rv, tmp_path):
+    cfg = rv.RvConfig()
+    flat = rv.weights.init_weights(cfg, seed=2)
+    rv.weights.save(str(tmp_path / "w.npz"), cfg, flat)
+    back = rv.weights.load(str(tmp_path / "w"), cfg)
+    assert all((back[k] == flat[k]).all() for k in flat)
+
+
+def test_config_struct_mirrors_header(rv):
+    """Field order and count of the ctypes image == struct RvConfig in include/ravvent_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "ravvent_hip.h")).read()
+    body = hdr[hdr.index("typedef struct RvConfig {"):hdr.index("} RvConfig;")]
+    names = re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, re.M)
+    assert names == [f[0] for f in rv.config.CRvConfig._fields_]
+    assert ctypes.sizeof(rv.config.CRvConfig) == 4 * len(names)
+    c = rv.RvConfig(mode="event", attention="bahdanau").to_c()
+    assert (c.mode, c.attention, c.vocab, c.start_token, c.end_token) == (1, 1, 7, 2, 1)
+
+
+def test_tokenizer_and_padding(rv):
+    dl = rv.data_loader
+    assert dl.nuc_tk.word_index == {"": 0, "^": 1, "$": 2, "a": 3, "c": 4, "g": 5, "t": 6}     # data_loader.py:21
+    assert dl.nuc_tk.texts_to_sequences(["$ACGT^", "$xTT^"]) == [[2, 3, 4, 5, 6, 1], [2, 6, 6, 1]]
+    assert dl.nuc_tk.sequences_to_texts([[2, 3, 0, 6, 1]]) == ["$ a  t ^"]
+    p = dl.pad_input_snippets([np.ones((3, 5)), np.ones((40, 5))], 30)
+    assert p.shape == (2, 30, 5) and p.dtype == np.float32 and p[0, 3:].sum() == 0 and p[1].sum() == 150
+    t = dl.pad_sequences([[2, 3, 1], [2, 1]], dtype="int64", value=0)
+    assert t.tolist() == [[2, 3, 1], [2, 1, 0]]
+    assert (rv.utils.input_mask(p, 0.0)[0] == np.r_[np.ones(3, bool), np.zeros(27, bool)]).all()
+
+
+def test_unpack_and_slab_split(rv):
+    data = ("r", "e", "t")
+    assert rv.utils.unpack_data_to_input_target(data, "raw") == ("r", "t")
+    assert rv.utils.unpack_data_to_input_target(data, "event") == ("e", "t")
+    assert rv.utils.unpack_data_to_input_target(data, "joint") == (("r", "e"), "t")
+    parts = rv.evaluator.PerformanceEvaluator._split_into_chunks(np.arange(2500), 1024)
+    assert [len(p) for p in parts] == [1024, 1024, 452]          # ravvent_performance_evaluator.py:19-22
+
+
+def test_shard_ranges_cover_contiguously(rv):
+    for n in (0, 1, 7, 256, 1025):
+        for world in (1, 2, 3, 8):
+            r = [rv.dist.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_library_exports_every_declared_symbol(rv):
+    """The C-ABI library loads on a GPU-less host and exports exactly what the header declares;
+    no compute entry point is called here."""
+    hdr = open(os.path.join(ROOT, "include", "ravvent_hip.h")).read()
+    declared = set(re.findall(r"\b(rv_\w+)\s*\(", hdr)) - {"rv_handle"}
+    lib = rv._capi.load_library()
+    assert declared == {n for n, _, _ in rv._capi.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.rv_abi_version() == 1
+
+
+def test_no_cpu_fallback(rv):
+    """Without a GPU the product path fails loudly (RV_EHIP), it never computes on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rv._capi.RavventHipError, match="no HIP device|RV_EHIP"):
+        rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0)
+    with pytest.raises(NotImplementedError):
+        rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, rnn_type="gru")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ravvent-basecaller_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "ravvent_oracle" not in src, f
