@@ -52,41 +52,58 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // z = [attention | h] . [W_dec[V:] ; U_dec] + W_dec[token] + b  (cell input = concat(one_hot, attention),
 // SURVEY.md A.4; the one-hot product is a row gather).
 // Workgroup = 64 beam rows x 16 units x 4 gates, K = 256 in one shot: the 64 KB activation panel and
-// the 64 KB weight panel (pre-transposed to [col][k] at load time, so both panels are straight row
-// copies) are pulled into LDS with every load in flight, ONE barrier, then each of the 8 waves runs
-// 2 x 64 MFMAs (16 rows x one gate's 16 units per tile, operands read as float4 along k) and the
-// four gate tiles meet in LDS for the cell update.  Operand re-reads from L2: x8 for activations,
-// x20 for weights (vs x32 / x80 for the register-only version this replaces).
+// the 64 KB weight panel (pre-transposed to [col][k] at load time, so both are coalesced 1 KB row
+// copies) go to LDS with every load in flight -- the epilogue's token / bias / cell-state operands are
+// fetched first so their round trips hide under the panels -- ONE barrier, then each of the 8 waves
+// runs 2 x 64 MFMAs (16 rows x one gate's 16 units per tile, operands read as float4 along k) and the
+// four gate tiles meet in LDS for the cell update.  (Measured alternatives: fragments straight from
+// global to registers 14 us -- 64 cache lines per load instruction; 32-row tiles 12 us -- two
+// rounds of workgroups; this form 8-10 us.)
 constexpr int CELL_LD = 260;                       // padded row length of the LDS panels (floats)
-constexpr int CELL_LDS_FLOATS = 2 * 64 * CELL_LD + 4 * 64 * 17;
+constexpr int CELL_ROWS = 64;
+constexpr int CELL_LDS_FLOATS = (CELL_ROWS + 64) * CELL_LD + 4 * CELL_ROWS * 17;
 __global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __restrict__ WcatT,
                                                   const float* __restrict__ Wtok, const float* __restrict__ bias,
                                                   int step) {
   if (step > 0 && d.nfin[step - 1] >= d.B) return;
   extern __shared__ __align__(16) float csm[];
-  float* As = csm;                        // [64 rows][260]
-  float* Bs = csm + 64 * CELL_LD;         // [64 cols = 4 gates x 16 units][260]
-  float* zs = csm + 2 * 64 * CELL_LD;     // [4 gates][64 rows][17]
+  float* As = csm;                                  // [64 rows][260]
+  float* Bs = csm + CELL_ROWS * CELL_LD;            // [64 cols = 4 gates x 16 units][260]
+  float* zs = csm + (CELL_ROWS + 64) * CELL_LD;     // [4 gates][64 rows][17]
   const int N = d.B * d.W;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r0 = blockIdx.y * 64, u0 = blockIdx.x * 16;
-  {
-    float4 ra[8], rb[8];
+  const int r0 = blockIdx.y * CELL_ROWS, u0 = blockIdx.x * 16;
+  // epilogue operands first (their round trips hide under the panel loads): thread = 2 x (row, unit)
+  int en[2]; float ec[2], eb[4], ew[2][4];
+  const int eun = tid & 15, ecol = u0 + eun;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;      // 64 float4 per 1 KB row
-      const int n = min(r0 + row, N - 1);
-      ra[p] = *reinterpret_cast<const float4*>(d.xh + (size_t)n * RV_E + 4 * c4);
-      const int col = (row >> 4) * RV_U + u0 + (row & 15);               // panel row = gate*16 + unit
-      rb[p] = *reinterpret_cast<const float4*>(WcatT + (size_t)col * RV_E + 4 * c4);
-    }
+  for (int gg = 0; gg < 4; ++gg) eb[gg] = bias[gg * RV_U + ecol];
+  int etok[2];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;
-      *reinterpret_cast<float4*>(As + row * CELL_LD + 4 * c4) = ra[p];
-      *reinterpret_cast<float4*>(Bs + row * CELL_LD + 4 * c4) = rb[p];
-    }
+  for (int p = 0; p < 2; ++p) {
+    en[p] = min(r0 + (tid >> 4) + 32 * p, N - 1);
+    etok[p] = d.tok[en[p]];
+    ec[p] = d.c[(size_t)en[p] * RV_U + ecol];
   }
+  float4 ra[8], rb[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;        // 64 float4 per 1 KB row
+    const int n = min(r0 + row, N - 1);
+    ra[p] = *reinterpret_cast<const float4*>(d.xh + (size_t)n * RV_E + 4 * c4);
+    const int col = (row >> 4) * RV_U + u0 + (row & 15);                 // panel row = gate*16 + unit
+    rb[p] = *reinterpret_cast<const float4*>(WcatT + (size_t)col * RV_E + 4 * c4);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;
+    *reinterpret_cast<float4*>(As + row * CELL_LD + 4 * c4) = ra[p];
+    *reinterpret_cast<float4*>(Bs + row * CELL_LD + 4 * c4) = rb[p];
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)       // one-hot row gather; lands while the MFMAs run
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) ew[p][gg] = Wtok[(size_t)etok[p] * RV_G + gg * RV_U + ecol];
   __syncthreads();
   const int rq = wv & 3, gh = wv >> 2;            // wave = 16-row quarter x gate pair
   const int li = lane & 15, kq = lane >> 4;       // lane group kq supplies k in [64kq, 64kq+64)
@@ -106,23 +123,20 @@ __global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __res
     }
     // C/D map of the 16x16 tile: col = lane & 15, row = 4*(lane >> 4) + reg
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zs[(g * 64 + 16 * rq + 4 * kq + r) * 17 + li] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) zs[(g * CELL_ROWS + 16 * rq + 4 * kq + r) * 17 + li] = acc0[r] + acc1[r];
   }
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int idx = tid + 512 * p, row = idx >> 4, un = idx & 15;
-    const int n = r0 + row;
-    if (n < N) {
-      const int col = u0 + un;
-      const float* wt = Wtok + (size_t)d.tok[n] * RV_G + col;
-      const float zi = zs[(0 * 64 + row) * 17 + un] + wt[0] + bias[col];
-      const float zf = zs[(1 * 64 + row) * 17 + un] + wt[RV_U] + bias[RV_U + col];
-      const float zg = zs[(2 * 64 + row) * 17 + un] + wt[2 * RV_U] + bias[2 * RV_U + col];
-      const float zo = zs[(3 * 64 + row) * 17 + un] + wt[3 * RV_U] + bias[3 * RV_U + col];
-      const float c2 = fmaf(rv_sigmoid(zf), d.c[(size_t)n * RV_U + col], rv_sigmoid(zi) * rv_tanh(zg));
-      d.c_new[(size_t)n * RV_U + col] = c2;
-      d.h_new[(size_t)n * RV_U + col] = rv_sigmoid(zo) * rv_tanh(c2);
+    const int row = (tid >> 4) + 32 * p;
+    if (r0 + row < N) {
+      const float zi = zs[(0 * CELL_ROWS + row) * 17 + eun] + ew[p][0] + eb[0];
+      const float zf = zs[(1 * CELL_ROWS + row) * 17 + eun] + ew[p][1] + eb[1];
+      const float zg = zs[(2 * CELL_ROWS + row) * 17 + eun] + ew[p][2] + eb[2];
+      const float zo = zs[(3 * CELL_ROWS + row) * 17 + eun] + ew[p][3] + eb[3];
+      const float c2 = fmaf(rv_sigmoid(zf), ec[p], rv_sigmoid(zi) * rv_tanh(zg));
+      d.c_new[(size_t)en[p] * RV_U + ecol] = c2;
+      d.h_new[(size_t)en[p] * RV_U + ecol] = rv_sigmoid(zo) * rv_tanh(c2);
     }
   }
 }
@@ -577,11 +591,34 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
     for (int m = 0; m < 4; ++m) pv[slot][m] = *reinterpret_cast<const float4*>(p + 64 * m);
     pm[slot] = mrow[t];
   };
-  att_prologue<W>(d, S, q, hcT, row0, tid);            // small loads first: vmcnt retires in issue order
+  // small loads first, INTO REGISTERS (vmcnt retires in issue order), then the stream, then the LDS
+  // writes: the prologue waits one short round trip while the value rows are already in flight.
+  constexpr int NC = (W * RV_U + ATT_THREADS - 1) / ATT_THREADS;
+  float hr[NC], cr[NC], wfr[2];
+  int sm0 = 0, sm2 = 0; float sm1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int idx = tid + ATT_THREADS * i;
+    hr[i] = idx < W * RV_U ? d.h_new[row0 * RV_U + idx] : 0.f;
+    cr[i] = idx < W * RV_U ? d.c_new[row0 * RV_U + idx] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int idx = tid + ATT_THREADS * i; wfr[i] = idx < RV_U * d.V ? d.W_fc[idx] : 0.f; }
+  const float bfr = tid < d.V ? d.b_fc[tid] : 0.f;
+  if (tid < W) { sm0 = d.finished[row0 + tid]; sm1 = d.log_probs[row0 + tid]; sm2 = d.lengths[row0 + tid]; }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < PD; ++k) issue(k, k);            // the stream starts before any math
   __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int idx = tid + ATT_THREADS * i;
+    if (idx < W * RV_U) { q[idx] = hr[i]; hcT[(idx & 127) * WB + (idx >> 7)] = hr[i]; S.cnew[idx] = cr[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int idx = tid + ATT_THREADS * i; if (idx < RV_U * d.V) S.wfc[idx] = wfr[i]; }
+  if (tid < d.V) S.wfc[RV_U * d.V + tid] = bfr;
+  if (tid < W) { S.fin[tid] = sm0; S.lprob[tid] = sm1; S.len[tid] = sm2; }
   __syncthreads();
   RV_STAMP(d, step, 1);
   // q' = W_mem . q (times log2 e): thread = (4 columns, 1 of 8 j-groups of 16), W_memT is [128][256]
@@ -829,7 +866,7 @@ void launch_dec_cell(const DecState& d, const float* WcatT, const float* Wtok, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     configured = true;
   }
-  hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + 63) / 64), dim3(512), shm, s, d, WcatT, Wtok, bias, step);
+  hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + CELL_ROWS - 1) / CELL_ROWS), dim3(512), shm, s, d, WcatT, Wtok, bias, step);
 }
 template <int W, int TB, int TD>
 static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {

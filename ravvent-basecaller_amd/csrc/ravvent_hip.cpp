@@ -46,7 +46,7 @@ struct RvContext {
   LstmW dec{};
   float* d_WmemT = nullptr;                 // derived: W_mem^T [128][256]
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
-  int lflash = 0;
+  int lflash = 0, lkeys = 0;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
@@ -275,8 +275,13 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0);
   if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r);
 
-  // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem
-  {
+  // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem.  The single-pass Luong
+  //      attend never reads keys (score_t = values_t . (W_mem q)); they are built for the two-pass
+  //      kernel and for the "keys" debug tap only.
+  const int W_eff = greedy ? 1 : W;
+  h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && W_eff <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
+  h->lkeys = (!h->lflash || h->opt_taps) ? 1 : 0;
+  if (h->lkeys) {
     GemmArgs g{};
     g.A = h->enc_out; g.lda = RV_E; g.Bm = h->W_mem; g.ldb = RV_U; g.C = h->keys; g.ldc = RV_U;
     g.M = B * Tm; g.N = RV_U; g.K = RV_E; g.row_mask = h->mask;
@@ -292,7 +297,6 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   d.keys = h->keys; d.values = h->enc_out; d.mask = h->mask;
   d.W_att = h->W_att; d.W_fc = h->W_fc; d.b_fc = h->b_fc; d.W_q = h->W_q; d.v_att = h->v_att;
   const int N = B * d.W;
-  h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && d.W <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
   if (h->opt_taps) {
     const size_t need = (size_t)steps * N * Tm;
     if (need > h->step_align_cap) {
@@ -506,7 +510,10 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
   const DecState& d = h->dec_st;
   if (!strcmp(name, "enc_output")) { src = h->enc_out; n = B * Tm * RV_E; }
   else if (!strcmp(name, "mask")) { src = h->mask; n = B * Tm; kind = 2; }
-  else if (!strcmp(name, "keys")) { src = h->keys; n = B * Tm * RV_U; }
+  else if (!strcmp(name, "keys")) {
+    if (!h->lkeys) return fail(h, RV_ESTATE, "keys were not built by the last call (single-pass attend); set debug_taps=1");
+    src = h->keys; n = B * Tm * RV_U;
+  }
   else if (!strcmp(name, "dbg_stamps")) {
     if (!d.dbg_ts) return fail(h, RV_ESTATE, "set RV_DBG_STAMPS=1 before rv_create");
     long long ts[16];
