@@ -36,28 +36,33 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
         "lstm_rec_event_l0": B * T_e * (rec + 2 * 5 * 512 * 2),
         "lstm_rec_raw_l1p": B * T_r * rec,
         "lstm_rec_event_l1p": B * T_e * rec,
-        "gemm_inproj_raw": B * T_r * 256 * 512 * 2,      # one direction per launch
-        "gemm_inproj_event": B * T_e * 256 * 512 * 2,
+        "gemm_inproj_raw": B * T_r * 256 * 1024 * 2,     # both directions per launch
+        "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
         "decode_graph": B * W * S * (369408 + 768 * Tm),
     }.get(kernel)
 
 
-def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=1024):
+def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=0, target_s=12.0):
     """The C restatement of the oracle (oracle/ravvent_cpu.c, 'port') timed on this host's cores
-    on a bounded sample of the same workload."""
+    on a bounded sample of the same workload: a 256-chunk probe sizes the sample to ~target_s
+    seconds of CPU work (sample_chunks > 0 fixes it instead)."""
     from oracle import cpu_port                       # checker / baseline only
-    raw, ev, _ = rv.synthetic.make_slab(sample_chunks, T_r, T_e, seed=100)
     blob = rv.weights.pack(cfg, flat)
     cores = cpu_port.max_threads()
-    cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, raw[:32], ev[:32], W, L)   # warm-up
+    run = lambda r, e: cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, r, e, W, L)
+    raw, ev, _ = rv.synthetic.make_slab(256, T_r, T_e, seed=100)
+    run(raw[:32], ev[:32])                            # warm-up (thread pool, page faults)
+    t0 = time.perf_counter(); run(raw, ev); probe = time.perf_counter() - t0
+    n = sample_chunks or int(min(max(256, round(target_s / probe) * 256), 16384))
+    raw, ev, _ = rv.synthetic.make_slab(n, T_r, T_e, seed=101)
     t0 = time.perf_counter()
-    tok, _ = cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, raw, ev, W, L)
+    tok, _ = run(raw, ev)
     dt = time.perf_counter() - t0
-    return {"value": round(sample_chunks / dt * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
-            "chunks_per_s": round(sample_chunks / dt, 2), "cores": cores, "kind": "port",
-            "sample": f"{sample_chunks} chunks of the same workload (joint {T_r}+{T_e}, beam {W}, L {L}), "
-                      f"{dt:.1f} s wall, S={tok.shape[1]}"}
+    return {"value": round(n / dt * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
+            "chunks_per_s": round(n / dt, 2), "cores": cores, "kind": "port",
+            "sample": f"{n} chunks of the same workload (joint {T_r}+{T_e}, beam {W}, L {L}) in slabs of the "
+                      f"C port's choosing, {dt:.1f} s wall on {cores} threads, S={tok.shape[1]}"}
 
 
 def main():
@@ -71,7 +76,7 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="chunks for the CPU baseline (0 = size to ~12 s)")
     args = ap.parse_args()
 
     import numpy as np

@@ -39,6 +39,8 @@ struct GemmArgs {
   const uint8_t* row_mask;     // [M] or nullptr: masked-off rows are written as 0
   const int* gather_idx;       // [M] or nullptr: adds gather_tab[gather_idx[m]*ld_tab + n]
   const float* gather_tab; int ld_tab;
+  // optional second problem sharing A (blockIdx.z == 1): the other LSTM direction of the same layer
+  const float* Bm1; const float* bias1; float* C1;
   const int* skip_flag; int skip_when;   // if skip_flag && *skip_flag >= skip_when: kernel exits
 };
 void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s);
@@ -80,7 +82,8 @@ struct DecState {
   float* step_logits;     // [L-1,B,W,V]   (greedy or debug) or nullptr
   float* step_align;      // [L-1,B,W,Tm]  (debug) or nullptr
   int* nfin;              // [L] chunks-finished counter per step
-  int* S_dev;             // [1]
+  int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
+  int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)
 };
@@ -90,6 +93,8 @@ void launch_dec_cell(const DecState& d, const float* WcatT /*[512,256] = ([W_dec
 // flash: single-pass Luong attend over `values` only (WmemT = W_mem^T [128,256]); else the two-pass kernel
 void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
+struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; };
+void launch_dec_reduce_steps(const DecParts& p, hipStream_t s);   // S_dev[0] = max_g S_g, S_dev[1+g] = S_g
 
 // ---------------------------------------------------------------- device math helpers
 #ifdef __HIPCC__

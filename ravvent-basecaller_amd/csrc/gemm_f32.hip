@@ -18,45 +18,48 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int KV = BK / 4;                 // float4 per A row per K tile
   constexpr int LDA_S = BM + 2, LDB_S = BN + 4;
   __shared__ __align__(16) float As[2][BK * LDA_S];
   __shared__ __align__(16) float Bs[2][BK * LDB_S];
 
   if (a.skip_flag && *a.skip_flag >= a.skip_when) return;
+  if (blockIdx.z == 1) { a.Bm = a.Bm1; a.bias = a.bias1; a.C = a.C1; }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int nk = a.K / BK;
 
-  float4 ra[TM], rb[TN];
+  constexpr int NA = TM * KV / 4, NB = TN * KV / 4;   // float4 loads per thread per K tile
+  float4 ra[NA], rb[NB];
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
 #pragma unroll
-    for (int p = 0; p < TM; ++p) {
-      const int idx = tid + 256 * p, row = idx >> 2, kv = idx & 3;
+    for (int p = 0; p < NA; ++p) {
+      const int idx = tid + 256 * p, row = idx / KV, kv = idx % KV;
       const int m = m0 + row;
       ra[p] = m < a.M ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kv)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int p = 0; p < TN; ++p) {
+    for (int p = 0; p < NB; ++p) {
       const int idx = tid + 256 * p, kr = idx / (BN / 4), nv = idx % (BN / 4);
       rb[p] = *reinterpret_cast<const float4*>(a.Bm + (size_t)(k0 + kr) * a.ldb + n0 + 4 * nv);
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < TM; ++p) {
-      const int idx = tid + 256 * p, row = idx >> 2, kv = idx & 3;
+    for (int p = 0; p < NA; ++p) {
+      const int idx = tid + 256 * p, row = idx / KV, kv = idx % KV;
       float* d = &As[buf][(4 * kv) * LDA_S + row];
       d[0] = ra[p].x; d[LDA_S] = ra[p].y; d[2 * LDA_S] = ra[p].z; d[3 * LDA_S] = ra[p].w;
     }
 #pragma unroll
-    for (int p = 0; p < TN; ++p) {
+    for (int p = 0; p < NB; ++p) {
       const int idx = tid + 256 * p, kr = idx / (BN / 4), nv = idx % (BN / 4);
       *reinterpret_cast<float4*>(&Bs[buf][kr * LDB_S + 4 * nv]) = rb[p];
     }
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s) {
   if (small_tile) {
     dim3 grid(a.N / 64, (a.M + 63) / 64);
-    hipLaunchKernelGGL((k_gemm_f32<1, 1>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_gemm_f32<1, 1, 16>), grid, dim3(256), 0, s, a);
   } else {
-    dim3 grid(a.N / 128, (a.M + 127) / 128);
-    hipLaunchKernelGGL((k_gemm_f32<2, 2>), grid, dim3(256), 0, s, a);
+    dim3 grid(a.N / 128, (a.M + 127) / 128, a.Bm1 ? 2 : 1);
+    hipLaunchKernelGGL((k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, s, a);
   }
 }

@@ -24,9 +24,9 @@ struct LstmW { const float *W, *U, *b; };
 struct ProfEntry { double ms = 0; int64_t n = 0; };
 
 struct GraphKey {
-  int B, W, Tm, L, greedy, taps;
+  int B, W, Tm, L, greedy, taps, split;
   bool operator<(const GraphKey& o) const {
-    return std::tie(B, W, Tm, L, greedy, taps) < std::tie(o.B, o.W, o.Tm, o.L, o.greedy, o.taps);
+    return std::tie(B, W, Tm, L, greedy, taps, split) < std::tie(o.B, o.W, o.Tm, o.L, o.greedy, o.taps, o.split);
   }
 };
 
@@ -45,6 +45,9 @@ struct RvContext {
   std::vector<std::vector<LstmW>> enc[2];   // [enc][layer][dir]
   LstmW dec{};
   float* d_WmemT = nullptr;                 // derived: W_mem^T [128][256]
+  int opt_split = 1;                        // concurrent decode sub-slabs (1..4); measured neutral at B=256
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
@@ -211,11 +214,12 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       launch_lstm_rec(a, F, bt, s);
     } else {
       const float* in = h->act[e][(l - 1) & 1];
-      for (int dr = 0; dr < 2; ++dr) {
+      {   // both directions in ONE launch (same A): 2x the workgroups -> less round quantisation
         GemmArgs g{};
-        g.A = in; g.lda = RV_E; g.Bm = h->enc[e][l][dr].W; g.ldb = RV_G;
-        g.C = h->xw + dr * RV_G; g.ldc = 2 * RV_G;
-        g.M = B * T; g.N = RV_G; g.K = RV_E; g.bias = h->enc[e][l][dr].b;
+        g.A = in; g.lda = RV_E; g.ldb = RV_G; g.ldc = 2 * RV_G;
+        g.M = B * T; g.N = RV_G; g.K = RV_E;
+        g.Bm = h->enc[e][l][0].W; g.bias = h->enc[e][l][0].b; g.C = h->xw;
+        g.Bm1 = h->enc[e][l][1].W; g.bias1 = h->enc[e][l][1].b; g.C1 = h->xw + RV_G;
         Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event");
         launch_gemm_f32(g, false, s);
       }
@@ -314,16 +318,55 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   }
   HIPCHK(h, hipMemsetAsync(d.xh, 0, sizeof(float) * N * RV_E, s));
   HIPCHK(h, hipMemsetAsync(d.c, 0, sizeof(float) * N * RV_U, s));
-  launch_dec_init(d, s);
 
+  // The slab decodes as `nsplit` independent sub-slabs on concurrent streams (inside one hipGraph):
+  // while one sub-slab is in its HBM-bound attention sweep another runs its latency-bound cell /
+  // output / beam phases.  Chunks never interact, and a sub-slab that finishes early is extended by
+  // k_dec_finalize exactly as the reference's whole-slab loop would (beam search only; greedy rows
+  // keep sampling after their end token, so greedy decodes as one piece).
+  int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
+  const int Wd = d.W;
+  DecState part[4];
+  DecParts parts{};
+  parts.n = nsplit; parts.steps = steps; parts.S_dev = d.S_dev;
+  for (int g = 0; g < nsplit; ++g) {
+    const size_t b0 = (size_t)B * g / nsplit, b1 = (size_t)B * (g + 1) / nsplit;
+    DecState& p = part[g];
+    p = d;
+    p.part = g; p.B = (int)(b1 - b0);
+    p.keys += b0 * Tm * RV_U; p.values += b0 * Tm * RV_E; p.mask += b0 * Tm;
+    p.xh += b0 * Wd * RV_E; p.z += b0 * Wd * RV_G;
+    p.c += b0 * Wd * RV_U; p.c_new += b0 * Wd * RV_U; p.h_new += b0 * Wd * RV_U;
+    p.tok += b0 * Wd; p.log_probs += b0 * Wd; p.finished += b0 * Wd; p.lengths += b0 * Wd;
+    p.step_ids += (size_t)steps * Wd * b0; p.parent_ids += (size_t)steps * Wd * b0; p.step_scores += (size_t)steps * Wd * b0;
+    if (p.step_logits) p.step_logits += (size_t)steps * Wd * V * b0;
+    if (p.step_align) p.step_align += (size_t)steps * Wd * Tm * b0;
+    p.nfin = d.nfin + g * (c.max_output_len + 1);
+    parts.nfin[g] = p.nfin; parts.B[g] = p.B;
+    launch_dec_init(p, s);
+  }
+  auto enqueue = [&](bool profiled) -> int {
+    for (int g = 1; g < nsplit; ++g) {
+      HIPCHK(h, hipEventRecord(h->ev_fork, s));
+      HIPCHK(h, hipStreamWaitEvent(h->side[g - 1], h->ev_fork, 0));
+    }
+    for (int g = 0; g < nsplit; ++g) launch_decode_steps(h, part[g], g == 0 ? s : h->side[g - 1], profiled && nsplit == 1);
+    for (int g = 1; g < nsplit; ++g) {
+      HIPCHK(h, hipEventRecord(h->ev_join[g - 1], h->side[g - 1]));
+      HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[g - 1], 0));
+    }
+    return RV_OK;
+  };
   if (h->opt_graph && h->opt_profile != 2) {
-    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash};
+    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash, nsplit};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t graph = nullptr;
       HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      launch_decode_steps(h, d, s, false);
-      HIPCHK(h, hipStreamEndCapture(s, &graph));
+      const int rc = enqueue(false);
+      hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc != RV_OK) return rc;
+      HIPCHK(h, ce);
       hipGraphExec_t exec = nullptr;
       HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       hipGraphDestroy(graph);
@@ -332,12 +375,22 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     Scope sc(h, "decode_graph");
     HIPCHK(h, hipGraphLaunch(it->second, s));
   } else {
-    launch_decode_steps(h, d, s, h->opt_profile == 2);
+    if (h->opt_profile == 2) nsplit = 1, parts.n = 1;     // per-kernel events need one stream
+    if (nsplit == 1) { part[0] = d; part[0].part = 0; part[0].nfin = d.nfin; parts.nfin[0] = d.nfin; parts.B[0] = B; launch_dec_init(part[0], s); }
+    const int rc = enqueue(h->opt_profile == 2);
+    if (rc != RV_OK) return rc;
   }
 
   int32_t* tk = dev_out ? tokens : h->out_tokens;
   float* o2 = dev_out ? out2 : h->out2;
-  { Scope sc(h, "dec_finalize"); launch_dec_finalize(d, tk, o2, s); }
+  {
+    Scope sc(h, "dec_finalize");
+    launch_dec_reduce_steps(parts, s);
+    for (int g = 0; g < parts.n; ++g) {
+      const size_t b0 = parts.n == 1 ? 0 : (size_t)B * g / parts.n;
+      launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s);
+    }
+  }
   int S = 0;
   HIPCHK(h, hipMemcpyAsync(&S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   if (!dev_out) {
@@ -427,8 +480,14 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &d.parent_ids, L * N));
   TRY(dalloc(h, &d.step_scores, L * N));
   TRY(dalloc(h, &d.step_logits, L * N * V));
-  TRY(dalloc(h, &d.nfin, L + 1));
-  TRY(dalloc(h, &d.S_dev, 1));
+  TRY(dalloc(h, &d.nfin, 4 * (L + 1)));
+  TRY(dalloc(h, &d.S_dev, 8));
+  for (int g = 0; g < 3; ++g) {
+    HIPTRY(hipStreamCreateWithFlags(&h->side[g], hipStreamNonBlocking));
+    HIPTRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+  }
+  HIPTRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  if (const char* e = getenv("RV_DECODE_SPLIT")) h->opt_split = atoi(e);
   TRY(dalloc(h, &h->out_tokens, B * L));
   TRY(dalloc(h, &h->out2, B * L * V));
 #undef TRY
@@ -444,6 +503,8 @@ void rv_destroy(rv_handle h) {
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) hipEventDestroy(e);
+  for (int g = 0; g < 3; ++g) { if (h->side[g]) hipStreamDestroy(h->side[g]); if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->step_align) hipFree(h->step_align);
   for (void* p : h->allocs) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -498,6 +559,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
+  else if (!strcmp(key, "decode_split")) h->opt_split = value < 1 ? 1 : (value > 4 ? 4 : value);
   else if (!strcmp(key, "profile")) h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value);
   else return fail(h, RV_EINVAL, "unknown option '%s'", key);
   return RV_OK;

@@ -13,4 +13,4 @@ for _ in range(3):
     bc.beam_search_prediction(x, 5, 48)
     ts = bc.get_tensor("dbg_stamps")
     names = ["entry", "prologue", "qprime", "sweep", "merge", "E att", "F logits", "G beam", "H/end"]
-    print(" ".join(f"{n}={ts[i]-ts[i-1] if i else 0:.0f}" for i, n in enumerate(names)), "total", ts[8])
+    print(" ".join(f"{n}={ts[i]-ts[i-1] if i else 0:.0f}" for i, n in enumerate(names[:8])), "total", ts[7])
