@@ -796,15 +796,11 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
   __shared__ int s_S;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int steps = d.L - 1, W = d.W, V = d.V;
-  if (tid == 0) {
-    int S = steps;
-    for (int s = 0; s < steps; ++s)
-      if (d.nfin[s] >= d.B) { S = s + 1; break; }
-    s_S = S;
-    if (b == 0) *d.S_dev = S;
-  }
-  __syncthreads();
-  const int S = s_S;
+  // S: steps the reference loop runs for the WHOLE slab (until every row is finished); So: steps this
+  // sub-slab actually ran.  For s in [So, S) all of its beams are finished: the reference emits the
+  // end token at an unchanged top-1 score there, which is what is written below.
+  const int S = d.S_dev[0], So = d.S_dev[1 + d.part];
+  (void)s_S;
   int32_t* tk = tokens + (size_t)b * steps;
   if (d.greedy) {
     for (int s = tid; s < steps; s += 64) {
@@ -814,7 +810,7 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
     }
     return;
   }
-  for (int i = tid; i < S * W; i += 64) {
+  for (int i = tid; i < So * W; i += 64) {
     const int s = i / W, w = i % W;
     s_ids[i] = d.step_ids[((size_t)s * d.B + b) * W + w];
     s_par[i] = d.parent_ids[((size_t)s * d.B + b) * W + w];
@@ -842,11 +838,27 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
   __syncthreads();
   for (int s = tid; s < steps; s += 64) {
     tk[s] = s < S ? s_tok[s] : d.pad_token;
-    out2[(size_t)b * steps + s] = s < S ? d.step_scores[((size_t)s * d.B + b) * W] : 0.f;
+    out2[(size_t)b * steps + s] = s < S ? d.step_scores[((size_t)min(s, So - 1) * d.B + b) * W] : 0.f;
   }
 }
 
+__global__ void k_dec_reduce_steps(DecParts p) {
+  int S = 0;
+  for (int g = 0; g < p.n; ++g) {
+    int Sg = p.steps;
+    for (int s = 0; s < p.steps; ++s)
+      if (p.nfin[g][s] >= p.B[g]) { Sg = s + 1; break; }
+    p.S_dev[1 + g] = Sg;
+    S = max(S, Sg);
+  }
+  p.S_dev[0] = S;
+}
+
 }  // namespace
+
+void launch_dec_reduce_steps(const DecParts& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_dec_reduce_steps, dim3(1), dim3(1), 0, s, p);
+}
 
 void launch_input_mask(const float* raw, const float* ev, int B, int T_r, int T_e, float pad,
                        uint8_t* mask, hipStream_t s) {

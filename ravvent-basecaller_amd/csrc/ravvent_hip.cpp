@@ -48,6 +48,7 @@ struct RvContext {
   int opt_split = 1;                        // concurrent decode sub-slabs (1..4); measured neutral at B=256
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int opt_side_ev = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
@@ -57,8 +58,8 @@ struct RvContext {
   float *d_raw = nullptr, *d_ev = nullptr;
   uint8_t* mask = nullptr;
   float* act[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [enc][pingpong]
-  float* xw = nullptr;
-  float* st[2][4] = {};     // [set][h_f, c_f, h_b, c_b]
+  float* xw[2] = {nullptr, nullptr};   // per encoder (the two encoders run on concurrent streams)
+  float* st[2][2][4] = {};             // [enc][set][h_f, c_f, h_b, c_b]
   float *enc_out = nullptr, *keys = nullptr;
   // decoder buffers
   DecState dec_st{};
@@ -148,8 +149,8 @@ void bind_weights(RvContext* h) {
 
 // ---- profiling: bracket a launch with events on the launch stream
 struct Scope {
-  RvContext* h; const char* name; hipEvent_t a = nullptr, b = nullptr; bool on;
-  Scope(RvContext* h_, const char* n) : h(h_), name(n), on(h_->opt_profile != 0) {
+  RvContext* h; const char* name; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
+  Scope(RvContext* h_, const char* n, hipStream_t st_ = nullptr) : h(h_), name(n), on(h_->opt_profile != 0), st(st_ ? st_ : h_->stream) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -158,11 +159,11 @@ struct Scope {
       return e;
     };
     a = get(); b = get();
-    hipEventRecord(a, h->stream);
+    hipEventRecord(a, st);
   }
   ~Scope() {
     if (!on) return;
-    hipEventRecord(b, h->stream);
+    hipEventRecord(b, st);
     h->pending.push_back({name, a, b});
   }
 };
@@ -188,10 +189,9 @@ int pick_rows_per_block(int B) {
 }
 
 // Encoder.call for one encoder (basecaller.py:48-59) writing into enc_out at time offset t_off.
-void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off) {
+void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s) {
   const int depth = h->cfg.enc_depth;
   const int bt = pick_rows_per_block(B);
-  hipStream_t s = h->stream;
   for (int l = 0; l < depth; ++l) {
     const bool last = l == depth - 1;
     float* out = last ? h->enc_out : h->act[e][l & 1];
@@ -202,15 +202,15 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
     for (int dr = 0; dr < 2; ++dr) {
       const LstmW& w = h->enc[e][l][dr];
       a.U[dr] = w.U;
-      a.h0[dr] = l > 0 ? h->st[rd][2 * dr] : nullptr;
-      a.c0[dr] = l > 0 ? h->st[rd][2 * dr + 1] : nullptr;
-      a.hT[dr] = h->st[wr][2 * dr];
-      a.cT[dr] = h->st[wr][2 * dr + 1];
+      a.h0[dr] = l > 0 ? h->st[e][rd][2 * dr] : nullptr;
+      a.c0[dr] = l > 0 ? h->st[e][rd][2 * dr + 1] : nullptr;
+      a.hT[dr] = h->st[e][wr][2 * dr];
+      a.cT[dr] = h->st[e][wr][2 * dr + 1];
     }
     if (l == 0) {
       a.x = x;
       for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
-      Scope sc(h, e == 0 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0");
+      Scope sc(h, e == 0 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0", s);
       launch_lstm_rec(a, F, bt, s);
     } else {
       const float* in = h->act[e][(l - 1) & 1];
@@ -218,13 +218,13 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         GemmArgs g{};
         g.A = in; g.lda = RV_E; g.ldb = RV_G; g.ldc = 2 * RV_G;
         g.M = B * T; g.N = RV_G; g.K = RV_E;
-        g.Bm = h->enc[e][l][0].W; g.bias = h->enc[e][l][0].b; g.C = h->xw;
-        g.Bm1 = h->enc[e][l][1].W; g.bias1 = h->enc[e][l][1].b; g.C1 = h->xw + RV_G;
-        Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event");
+        g.Bm = h->enc[e][l][0].W; g.bias = h->enc[e][l][0].b; g.C = h->xw[e];
+        g.Bm1 = h->enc[e][l][1].W; g.bias1 = h->enc[e][l][1].b; g.C1 = h->xw[e] + RV_G;
+        Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event", s);
         launch_gemm_f32(g, false, s);
       }
-      a.x = h->xw;
-      Scope sc(h, e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p");
+      a.x = h->xw[e];
+      Scope sc(h, e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p", s);
       launch_lstm_rec(a, 0, bt, s);
     }
   }
@@ -276,8 +276,21 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
 
   // ---- _encode_input (basecaller.py:395-416)
   { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
-  if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0);
-  if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r);
+  // The two encoders are independent until the time-axis concat (basecaller.py:400-405).  Running the
+  // short event chain on a side stream under the raw chain was measured neutral-to-negative at
+  // B = 256 (every recurrence workgroup needs a whole CU), so it is off unless asked for.
+  const bool side_ev = use_raw && use_ev && h->opt_side_ev;
+  hipStream_t sev = side_ev ? h->side[0] : s;
+  if (side_ev) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, s));
+    HIPCHK(h, hipStreamWaitEvent(sev, h->ev_fork, 0));
+  }
+  if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, sev);
+  if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
+  if (side_ev) {
+    HIPCHK(h, hipEventRecord(h->ev_join[0], sev));
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
+  }
 
   // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem.  The single-pass Luong
   //      attend never reads keys (score_t = values_t . (W_mem q)); they are built for the two-pass
@@ -459,9 +472,13 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
     if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
     if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
   }
-  if (c.enc_depth > 1) TRY(dalloc(h, &h->xw, B * Tx * 2 * RV_G));
-  for (int st = 0; st < 2; ++st)
-    for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[st][k], B * RV_U));
+  if (c.enc_depth > 1) {
+    if (use_raw) TRY(dalloc(h, &h->xw[0], B * Tr * 2 * RV_G));
+    if (use_ev) TRY(dalloc(h, &h->xw[1], B * Te * 2 * RV_G));
+  }
+  for (int e = 0; e < 2; ++e)
+    for (int st = 0; st < 2; ++st)
+      for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
   TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
   TRY(dalloc(h, &h->keys, B * Tm * RV_U));
   DecState& d = h->dec_st;
@@ -559,6 +576,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
+  else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "decode_split")) h->opt_split = value < 1 ? 1 : (value > 4 ? 4 : value);
   else if (!strcmp(key, "profile")) h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value);
   else return fail(h, RV_EINVAL, "unknown option '%s'", key);
