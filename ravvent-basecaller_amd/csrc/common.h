@@ -41,6 +41,7 @@ struct GemmArgs {
   const float* gather_tab; int ld_tab;
   // optional second problem sharing A (blockIdx.z == 1): the other LSTM direction of the same layer
   const float* Bm1; const float* bias1; float* C1;
+  int xcd_remap;               // 1: 1-D grid, the workgroups sharing an A tile are dealt to ONE XCD (L2 reuse)
   const int* skip_flag; int skip_when;   // if skip_flag && *skip_flag >= skip_when: kernel exits
 };
 void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s);

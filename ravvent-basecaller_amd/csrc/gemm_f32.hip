@@ -27,11 +27,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   __shared__ __align__(16) float Bs[2][BK * LDB_S];
 
   if (a.skip_flag && *a.skip_flag >= a.skip_when) return;
-  if (blockIdx.z == 1) { a.Bm = a.Bm1; a.bias = a.bias1; a.C = a.C1; }
+  // Tile coordinates.  Plain: (x = N tile, y = M tile, z = problem).  XCD-aware: workgroups are dealt
+  // round-robin to the 8 XCDs (private L2s), so ids {x, x+8, x+16, ...} share an XCD; the
+  // ntn*nprob workgroups that read the same A tile are made consecutive on ONE XCD -- the A
+  // panel is then fetched from HBM once instead of once per XCD (PMC: 8.4x -> ~1x the bytes).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_remap) {
+    const int ntn = a.N / BN, nprob = a.Bm1 ? 2 : 1, per = ntn * nprob;
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int combo = j % per;
+    by = (j / per) * 8 + xcd;
+    bx = combo % ntn; bz = combo / ntn;
+    if (by * BM >= a.M) return;
+  }
+  if (bz == 1) { a.Bm = a.Bm1; a.bias = a.bias1; a.C = a.C1; }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int nk = a.K / BK;
 
   constexpr int NA = TM * KV / 4, NB = TN * KV / 4;   // float4 loads per thread per K tile
@@ -126,7 +139,9 @@ void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s) {
     dim3 grid(a.N / 64, (a.M + 63) / 64);
     hipLaunchKernelGGL((k_gemm_f32<1, 1, 16>), grid, dim3(256), 0, s, a);
   } else {
-    dim3 grid(a.N / 128, (a.M + 127) / 128, a.Bm1 ? 2 : 1);
+    const int ntm = (a.M + 127) / 128, ntn = a.N / 128, nprob = a.Bm1 ? 2 : 1;
+    dim3 grid(ntn, ntm, nprob);
+    if (a.xcd_remap) grid = dim3(((ntm + 7) / 8) * 8 * ntn * nprob, 1, 1);
     hipLaunchKernelGGL((k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, s, a);
   }
 }

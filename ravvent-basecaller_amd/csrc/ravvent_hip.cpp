@@ -220,6 +220,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         g.M = B * T; g.N = RV_G; g.K = RV_E;
         g.Bm = h->enc[e][l][0].W; g.bias = h->enc[e][l][0].b; g.C = h->xw[e];
         g.Bm1 = h->enc[e][l][1].W; g.bias1 = h->enc[e][l][1].b; g.C1 = h->xw[e] + RV_G;
+        g.xcd_remap = 1;
         Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event", s);
         launch_gemm_f32(g, false, s);
       }
