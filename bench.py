@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 BASES_PER_CHUNK = 6
 PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 
 
 def algorithmic_flops(kernel, B, T_r, T_e, W, S):
@@ -40,6 +41,16 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
         "decode_graph": B * W * S * (369408 + 768 * Tm),
+        "dec_cell": B * W * 2 * 256 * 512,
+    }.get(kernel)
+
+
+def algorithmic_bytes(kernel, B, T_r, T_e, W, S):
+    """Algorithmic HBM bytes of ONE launch of an HBM-bound kernel."""
+    Tm = T_r + T_e
+    return {
+        # single-pass Luong attend: the chunk's values [T_m,256] fp32 once per step (+ mask bytes)
+        "dec_attend": B * Tm * (256 * 4 + 1),
     }.get(kernel)
 
 
@@ -76,6 +87,7 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-kernel event pass over the decode loop")
     ap.add_argument("--cpu-sample", type=int, default=0, help="chunks for the CPU baseline (0 = size to ~12 s)")
     args = ap.parse_args()
 
@@ -149,19 +161,48 @@ def main():
 
     if rank == 0:
         chunks_per_s = world * B * args.steps / dt
-        # dominant kernel = largest accumulated device time among the profiled launches
-        name, (ms, n) = max(prof.items(), key=lambda kv: kv[1][0])
-        fl = algorithmic_flops(name, B, T_r, T_e, W, S)
+        # Per-kernel view of the decode graph: a short extra pass with hipEvents around EVERY kernel
+        # (option profile=2: the graph is bypassed, same kernels, same stream).  Not part of `value`.
+        dec = {}
+        if not args.no_kernel_pass:
+            bc.set_option("profile", 2)
+            bc.reset_profile()
+            for _ in range(3):
+                step()
+            dec = {k: v for k, v in bc.profile().items() if k.startswith("dec_") and k != "dec_finalize"}
+            bc.set_option("profile", 1)
+        # time per slab of every kernel name (graph replaced by its members when available)
+        per_slab = {k: v[0] / args.steps for k, v in prof.items()}
+        if dec:
+            per_slab.pop("decode_graph", None)
+            for k, (ms, n) in dec.items():
+                per_slab[k] = ms / 3.0
+        name = max(per_slab, key=per_slab.get)                    # dominant kernel
+        ms, n = dec[name] if name in dec else prof[name]
         avg_ms = ms / max(n, 1)
-        achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
-                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
-                "avg_launch_ms": round(avg_ms, 4), "launches": n, "flops_per_launch": fl, "traffic": None}
+        by = algorithmic_bytes(name, B, T_r, T_e, W, S)
+        if by:
+            achieved = by / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": n,
+                    "bytes_per_launch": by, "traffic": None}
+        else:
+            fl = algorithmic_flops(name, B, T_r, T_e, W, S)
+            achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
+                    "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": n, "flops_per_launch": fl, "traffic": None}
+        roof["share_of_slab_time"] = round(per_slab[name] / sum(per_slab.values()), 3)
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                roof["traffic"] = json.load(f).get(name)
+                for k, v in json.load(f).items():
+                    if k.split("@")[0] == name and B == 256:          # collected on this workload only
+                        roof["traffic"] = v["hbm_bytes_per_launch"]
+        # whole-path view: algorithmic FLOPs of the path / step time vs the fp32 peak
+        path_fl = B * (T_r * 1050624 + T_e * 1058816 + (T_r + T_e) * 65536 + W * S * (369408 + 768 * (T_r + T_e)))
+        path_tf = world * path_fl / (dt / args.steps) / 1e12
         total_ms = sum(v[0] for v in prof.values())
         out = {
             "metric": "kbases/s, raw+event joint mode, beam=5 (hot path: beam_search_prediction)",
@@ -175,7 +216,10 @@ def main():
                        "decode_steps": S, "weights": "random-init (Keras defaults, seed 22)",
                        "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step" if world > 1 else "")},
             "roofline": roof,
+            "roofline_path": {"bound": "mfma", "achieved": round(path_tf, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
+                              "frac": round(path_tf / (PEAK_F32_TFLOPS * world), 4), "flops_per_chunk": path_fl // B},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+            "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
             "device_ms_per_step": round(total_ms / args.steps, 4),
             "step_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
         }
