@@ -842,22 +842,24 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
   }
 }
 
-__global__ void k_dec_reduce_steps(DecParts p) {
+// one wave: lane s looks at step s (max_output_len <= 64), ballot finds the first finished step
+__global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
+  const int lane = threadIdx.x;
   int S = 0;
   for (int g = 0; g < p.n; ++g) {
-    int Sg = p.steps;
-    for (int s = 0; s < p.steps; ++s)
-      if (p.nfin[g][s] >= p.B[g]) { Sg = s + 1; break; }
-    p.S_dev[1 + g] = Sg;
+    const bool done = lane < p.steps && p.nfin[g][lane] >= p.B[g];
+    const unsigned long long m = __ballot(done);
+    const int Sg = m ? __ffsll((long long)m) : p.steps;      // first finished step index + 1
+    if (lane == 0) p.S_dev[1 + g] = Sg;
     S = max(S, Sg);
   }
-  p.S_dev[0] = S;
+  if (lane == 0) p.S_dev[0] = S;
 }
 
 }  // namespace
 
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_dec_reduce_steps, dim3(1), dim3(1), 0, s, p);
+  hipLaunchKernelGGL(k_dec_reduce_steps, dim3(1), dim3(64), 0, s, p);
 }
 
 void launch_input_mask(const float* raw, const float* ev, int B, int T_r, int T_e, float pad,
