@@ -118,6 +118,15 @@ int rv_get_profile(rv_handle h, const char* kernel, double* total_ms, int64_t* l
 int rv_profile_names(rv_handle h, char* dst, size_t dst_bytes);
 int rv_reset_profile(rv_handle h);
 
+/* ---- host-side pre-processing ("next" row of the scope table; pure CPU, needs no handle) ----
+ * EventDetector.run (event_detection/event_detector.py:75-210): streaming two-window t-statistic
+ * event detection over one read's raw samples.  Outputs are parallel arrays of `capacity`
+ * entries; *n_events receives the number of events found (call with capacity 0 / NULL arrays to
+ * count).  Returns RV_EINVAL if capacity was too small. */
+int rv_detect_events(const double* raw, size_t n, int32_t window_length1, int32_t window_length2,
+                     double threshold1, double threshold2, double peak_height, int64_t* start,
+                     int64_t* length, double* mean, double* stdv, size_t capacity, size_t* n_events);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@ SYMBOLS = [
     ("rv_get_profile", c_int32, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),
     ("rv_profile_names", c_int32, [c_void_p, ctypes.c_char_p, c_size_t]),
     ("rv_reset_profile", c_int32, [c_void_p]),
+    ("rv_detect_events", c_int32, [c_void_p, c_size_t, c_int32, c_int32, c_double, c_double, c_double,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
 ]
 
 _lib = None

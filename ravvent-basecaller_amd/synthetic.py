@@ -35,3 +35,24 @@ def hash_slab(B, T_r, T_e, seed=0):
         if ep:
             ev[b, T_e - min(ep, T_e):] = 0.0
     return raw, ev
+
+
+def make_read(n_bases=600, seed=0, mean_dwell=9.0):
+    """A synthetic nanopore read in the reference's file form: int signal + labels
+    (start, end, base).  6-mer -> level table ~ N(0,1) from seed 1234 (DeepSimulator's pore model
+    is not available), dwell 5 + Geometric clipped to [3,40], Gaussian noise, quantised to int."""
+    rng = np.random.default_rng(seed)
+    bases = rng.integers(0, 4, n_bases)
+    table = np.random.default_rng(1234).standard_normal(4096)
+    kmer = np.zeros(n_bases, np.int64)
+    for i in range(n_bases):
+        k = 0
+        for j in range(6):
+            k = k * 4 + bases[min(max(i - 2 + j, 0), n_bases - 1)]
+        kmer[i] = k
+    dwell = np.clip(5 + rng.geometric(1.0 / max(mean_dwell - 5.0, 1.0), n_bases) - 1, 3, 40)
+    levels = np.repeat(table[kmer], dwell)
+    signal = np.round(500 + 80 * (levels + 0.15 * rng.standard_normal(levels.size))).astype(int)
+    ends = np.cumsum(dwell)
+    labels = np.column_stack([ends - dwell, ends, np.array(list("ACGT"))[bases]]).astype(object)
+    return signal, labels
