@@ -25,6 +25,29 @@ class PerformanceEvaluator:
         """ravvent_performance_evaluator.py:19-22"""
         return np.array_split(arr, np.arange(1, arr.shape[0] // def_chunk_size + 1) * def_chunk_size)
 
+    def run(self, signal_data_source, chunk_size: int = 1024):
+        """ravvent_performance_evaluator.py:24-87 for a `.signal` / `.label` file pair."""
+        from pathlib import Path
+        label_path = Path(signal_data_source).with_suffix(".label")
+        signal = np.loadtxt(signal_data_source, dtype=int)
+        labels = np.loadtxt(label_path, dtype=object)
+        return self.run_read(signal, labels, chunk_size=chunk_size)
+
+    def run_read(self, signal, labels, chunk_size: int = 1024, beam_width: int = 5):
+        """Same as run() from in-memory arrays: labels rows are (start, end, base)."""
+        from . import data_loader as dl
+        ranges_ids = np.asarray(labels)[:, :2].astype(int)
+        ref_seq = "".join(list(np.asarray(labels)[:, 2]))
+        samples_num = int(ranges_ids[-1, 1] - ranges_ids[0, 0])
+        start = timer()
+        slab = dl.snippets_to_slab(*dl.prepare_snippets(signal, ranges_ids, np.asarray(labels)[:, 2], self.stride))
+        t_chunking = timer() - start
+        res = self.run_slabs(*slab, bases_num=len(ref_seq), samples_num=samples_num, chunk_size=chunk_size,
+                             beam_width=beam_width)
+        res["t_data_loading"] += t_chunking
+        res["total"] += t_chunking
+        return res
+
     def run_slabs(self, raw_snippets, event_snippets, nuc_tk_snippets, bases_num=None, samples_num=None,
                   chunk_size: int = 1024, beam_width: int = 5):
         """The body of `run()` after data loading: inputs are the padded snippet arrays
