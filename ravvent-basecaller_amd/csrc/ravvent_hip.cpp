@@ -66,6 +66,10 @@ struct RvContext {
   float* step_align = nullptr; size_t step_align_cap = 0;
   int32_t* out_tokens = nullptr;
   float* out2 = nullptr;
+  // pinned host staging for the host-buffer entry points (pageable hipMemcpy is synchronous and slow)
+  float *pin_raw = nullptr, *pin_ev = nullptr, *pin_out2 = nullptr;
+  int32_t* pin_tok = nullptr;
+  int* pin_S = nullptr;
 
   int opt_taps = 0, opt_graph = 1, opt_profile = 0;
   std::map<std::string, ProfEntry> prof;
@@ -270,9 +274,15 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   hipStream_t s = h->stream;
   const int Tm = T_r + T_e, V = c.vocab, steps = L - 1;
   const float *xr = raw, *xe = ev;
-  if (!dev_in) {
-    if (use_raw) { HIPCHK(h, hipMemcpyAsync(h->d_raw, raw, sizeof(float) * B * T_r, hipMemcpyHostToDevice, s)); xr = h->d_raw; }
-    if (use_ev) { HIPCHK(h, hipMemcpyAsync(h->d_ev, ev, sizeof(float) * B * T_e * 5, hipMemcpyHostToDevice, s)); xe = h->d_ev; }
+  if (!dev_in) {   // host -> pinned staging (CPU memcpy) -> async H2D
+    if (use_raw) {
+      memcpy(h->pin_raw, raw, sizeof(float) * B * T_r);
+      HIPCHK(h, hipMemcpyAsync(h->d_raw, h->pin_raw, sizeof(float) * B * T_r, hipMemcpyHostToDevice, s)); xr = h->d_raw;
+    }
+    if (use_ev) {
+      memcpy(h->pin_ev, ev, sizeof(float) * B * T_e * 5);
+      HIPCHK(h, hipMemcpyAsync(h->d_ev, h->pin_ev, sizeof(float) * B * T_e * 5, hipMemcpyHostToDevice, s)); xe = h->d_ev;
+    }
   }
 
   // ---- _encode_input (basecaller.py:395-416)
@@ -405,14 +415,18 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
       launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s);
     }
   }
-  int S = 0;
-  HIPCHK(h, hipMemcpyAsync(&S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->pin_S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   if (!dev_out) {
-    HIPCHK(h, hipMemcpyAsync(tokens, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_tok, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
   }
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  const int S = *h->pin_S;
+  if (!dev_out) {
+    memcpy(tokens, h->pin_tok, sizeof(int32_t) * B * steps);
+    memcpy(out2, h->pin_out2, sizeof(float) * B * steps * (greedy ? V : 1));
+  }
   drain_profile(h);
   *S_out = S;
   h->lS = S;
@@ -508,6 +522,11 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   if (const char* e = getenv("RV_DECODE_SPLIT")) h->opt_split = atoi(e);
   TRY(dalloc(h, &h->out_tokens, B * L));
   TRY(dalloc(h, &h->out2, B * L * V));
+  HIPTRY(hipHostMalloc((void**)&h->pin_raw, std::max<size_t>(B * Tr, 1) * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_ev, std::max<size_t>(B * Te * 5, 1) * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_tok, B * L * sizeof(int32_t), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_out2, B * L * V * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocDefault));
 #undef TRY
 #undef HIPTRY
   *out = h;
@@ -524,6 +543,7 @@ void rv_destroy(rv_handle h) {
   for (int g = 0; g < 3; ++g) { if (h->side[g]) hipStreamDestroy(h->side[g]); if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->step_align) hipFree(h->step_align);
+  for (void* p : {(void*)h->pin_raw, (void*)h->pin_ev, (void*)h->pin_tok, (void*)h->pin_out2, (void*)h->pin_S}) if (p) hipHostFree(p);
   for (void* p : h->allocs) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;

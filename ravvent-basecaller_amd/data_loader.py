@@ -51,7 +51,10 @@ def tokens_to_strings(tokens) -> list:
     if t.ndim == 1:
         t = t[None]
     codes = _ASCII[np.clip(t, 0, 255).astype(np.uint8)]
-    return [row[row != 0].tobytes().decode("ascii") for row in codes]
+    keep = codes != 0
+    flat = codes[keep].tobytes().decode("ascii")          # one decode for the whole slab
+    ends = np.cumsum(keep.sum(axis=1)).tolist()
+    return [flat[a:b] for a, b in zip([0] + ends[:-1], ends)]
 
 
 def pad_sequences(seqs, maxlen=None, dtype="float32", value=0.0):
