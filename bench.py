@@ -114,19 +114,18 @@ def main():
     flat = bc.init_random_weights(seed=22)            # Keras-default initialisers, seed as ravvent.py:9
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=rank)
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
-    gathered = None
-    if world > 1:
-        gathered = (torch.empty((world * B, L - 1), dtype=torch.int32, device=dev),
-                    torch.empty((world * B, L - 1), dtype=torch.float32, device=dev))
+    packed = gathered = None
+    if world > 1:   # tokens (i32) and scores (f32 bits) travel in ONE fixed-shape all-gather per step
+        packed = torch.zeros((B, 2 * (L - 1)), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world * B, 2 * (L - 1)), dtype=torch.int32, device=dev)
 
     def step():
         tok, sc = bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
         if world > 1:   # the path's single exchange: gather every rank's calls (RCCL over xGMI)
             S = tok.shape[1]
-            pt = torch.zeros((B, L - 1), dtype=torch.int32, device=dev); pt[:, :S] = tok
-            ps = torch.zeros((B, L - 1), dtype=torch.float32, device=dev); ps[:, :S] = sc
-            dist.all_gather_into_tensor(gathered[0], pt)
-            dist.all_gather_into_tensor(gathered[1], ps)
+            packed[:, :S] = tok
+            packed[:, L - 1:L - 1 + S] = sc.view(torch.int32)
+            dist.all_gather_into_tensor(gathered, packed)
         return tok, sc
 
     def fence():
