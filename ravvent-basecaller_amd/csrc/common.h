@@ -61,11 +61,14 @@ struct DecState {
   const float* values;    // [B,Tm,256]  (= enc_output; masked positions never contribute)
   const uint8_t* mask;    // [B,Tm]
   // recurrent state, N = B*W rows
-  float* xh;              // [N,256] = [attention | h]  (cell GEMM A operand)
-  float* z;               // [N,512] gate pre-activations
-  float* c;               // [N,128]
-  float* c_new;           // [N,128]
-  float* h_new;           // [N,128]
+  // StackedRNNCells (basecaller.py:85-91): layer k's buffers sit at base + k * ls_* elements
+  int depth;              // decoder_depth
+  size_t ls_xh, ls_c;     // layer strides (elements) of xh and of c / c_new / h_new
+  float* xh;              // [depth][N,256]: layer 0 = [attention | h_0], layer k>=1 = [h_{k-1} (new) | h_k]
+  float* z;               // [N,512] gate pre-activations (unused by the fused cell kernel)
+  float* c;               // [depth][N,128]
+  float* c_new;           // [depth][N,128]
+  float* h_new;           // [depth][N,128]
   int* tok;               // [N]
   float* log_probs;       // [N]
   uint8_t* finished;      // [N]
@@ -89,7 +92,8 @@ struct DecState {
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)
 };
 void launch_dec_init(const DecState& d, hipStream_t s);
-void launch_dec_cell(const DecState& d, const float* WcatT /*[512,256] = ([W_dec[V:];U_dec])^T*/, const float* Wtok /*[V,512]*/,
+// layer: which stacked cell; Wtok (one-hot embedding rows) is non-null for layer 0 only
+void launch_dec_cell(const DecState& d, int layer, const float* WcatT /*[512,256] = ([W_in;U])^T*/, const float* Wtok /*[V,512]*/,
                      const float* bias /*[512]*/, int step, hipStream_t s);
 // flash: single-pass Luong attend over `values` only (WmemT = W_mem^T [128,256]); else the two-pass kernel
 void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s);

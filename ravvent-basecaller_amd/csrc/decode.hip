@@ -62,10 +62,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CELL_LD = 260;                       // padded row length of the LDS panels (floats)
 constexpr int CELL_ROWS = 64;
 constexpr int CELL_LDS_FLOATS = (CELL_ROWS + 64) * CELL_LD + 4 * CELL_ROWS * 17;
-__global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __restrict__ WcatT,
+__global__ __launch_bounds__(512) void k_dec_cell(DecState d, int layer, const float* __restrict__ WcatT,
                                                   const float* __restrict__ Wtok, const float* __restrict__ bias,
                                                   int step) {
   if (step > 0 && d.nfin[step - 1] >= d.B) return;
+  const float* xh_l = d.xh + layer * d.ls_xh;
+  const float* c_l = d.c + layer * d.ls_c;
+  float* cn_l = d.c_new + layer * d.ls_c;
+  float* hn_l = d.h_new + layer * d.ls_c;
+  float* xh_up = layer + 1 < d.depth ? d.xh + (layer + 1) * d.ls_xh : nullptr;   // next cell's input half
   extern __shared__ __align__(16) float csm[];
   float* As = csm;                                  // [64 rows][260]
   float* Bs = csm + CELL_ROWS * CELL_LD;            // [64 cols = 4 gates x 16 units][260]
@@ -82,15 +87,15 @@ __global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __res
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     en[p] = min(r0 + (tid >> 4) + 32 * p, N - 1);
-    etok[p] = d.tok[en[p]];
-    ec[p] = d.c[(size_t)en[p] * RV_U + ecol];
+    etok[p] = Wtok ? d.tok[en[p]] : 0;
+    ec[p] = c_l[(size_t)en[p] * RV_U + ecol];
   }
   float4 ra[8], rb[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int idx = tid + 512 * p, row = idx >> 6, c4 = idx & 63;        // 64 float4 per 1 KB row
     const int n = min(r0 + row, N - 1);
-    ra[p] = *reinterpret_cast<const float4*>(d.xh + (size_t)n * RV_E + 4 * c4);
+    ra[p] = *reinterpret_cast<const float4*>(xh_l + (size_t)n * RV_E + 4 * c4);
     const int col = (row >> 4) * RV_U + u0 + (row & 15);                 // panel row = gate*16 + unit
     rb[p] = *reinterpret_cast<const float4*>(WcatT + (size_t)col * RV_E + 4 * c4);
   }
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __res
 #pragma unroll
   for (int p = 0; p < 2; ++p)       // one-hot row gather; lands while the MFMAs run
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) ew[p][gg] = Wtok[(size_t)etok[p] * RV_G + gg * RV_U + ecol];
+    for (int gg = 0; gg < 4; ++gg) ew[p][gg] = Wtok ? Wtok[(size_t)etok[p] * RV_G + gg * RV_U + ecol] : 0.f;
   __syncthreads();
   const int rq = wv & 3, gh = wv >> 2;            // wave = 16-row quarter x gate pair
   const int li = lane & 15, kq = lane >> 4;       // lane group kq supplies k in [64kq, 64kq+64)
@@ -135,8 +140,10 @@ __global__ __launch_bounds__(512) void k_dec_cell(DecState d, const float* __res
       const float zg = zs[(2 * CELL_ROWS + row) * 17 + eun] + ew[p][2] + eb[2];
       const float zo = zs[(3 * CELL_ROWS + row) * 17 + eun] + ew[p][3] + eb[3];
       const float c2 = fmaf(rv_sigmoid(zf), ec[p], rv_sigmoid(zi) * rv_tanh(zg));
-      d.c_new[(size_t)en[p] * RV_U + ecol] = c2;
-      d.h_new[(size_t)en[p] * RV_U + ecol] = rv_sigmoid(zo) * rv_tanh(c2);
+      const float hh = rv_sigmoid(zo) * rv_tanh(c2);
+      cn_l[(size_t)en[p] * RV_U + ecol] = c2;
+      hn_l[(size_t)en[p] * RV_U + ecol] = hh;
+      if (xh_up) xh_up[(size_t)en[p] * RV_E + ecol] = hh;
     }
   }
 }
@@ -230,11 +237,13 @@ struct AttLds {
 template <int W>
 __device__ __forceinline__ void att_prologue(const DecState& d, AttShared& S, float* q, float* hcT, size_t row0, int tid) {
   const int V = d.V;
+  const float* hn_top = d.h_new + (d.depth - 1) * d.ls_c;
+  const float* cn_top = d.c_new + (d.depth - 1) * d.ls_c;
   for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
-    const float v = d.h_new[row0 * RV_U + i];
+    const float v = hn_top[row0 * RV_U + i];
     q[i] = v;
     hcT[(i & 127) * WB + (i >> 7)] = v;
-    S.cnew[i] = d.c_new[row0 * RV_U + i];
+    S.cnew[i] = cn_top[row0 * RV_U + i];
   }
   for (int i = tid; i < RV_U * V; i += ATT_THREADS) S.wfc[i] = d.W_fc[i];
   if (tid < V) S.wfc[RV_U * V + tid] = d.b_fc[tid];
@@ -364,12 +373,18 @@ __device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const 
   RV_STAMP(d, step, 7);
   if (d.dbg_stop == 7) return;
 
-  // H: next-step state, gathered by parent beam: xh = [attention | h], c
+  // H: next-step state of every stacked cell, gathered by parent beam: layer 0 input = [attention | h_0],
+  //    layer k input's own half = h_k, cell states c_k.  The top layer's h / c are already in LDS.
+  const int top = d.depth - 1;
   for (int i = tid; i < W * RV_U; i += ATT_THREADS) {
     const int w = i >> 7, e = i & 127, p = S.parent[w];
     d.xh[(row0 + w) * RV_E + e] = att[p * RV_U + e];
-    d.xh[(row0 + w) * RV_E + RV_U + e] = q[p * RV_U + e];
-    d.c[(row0 + w) * RV_U + e] = S.cnew[p * RV_U + e];
+    (d.xh + top * d.ls_xh)[(row0 + w) * RV_E + RV_U + e] = q[p * RV_U + e];
+    (d.c + top * d.ls_c)[(row0 + w) * RV_U + e] = S.cnew[p * RV_U + e];
+    for (int k = 0; k < top; ++k) {
+      (d.xh + k * d.ls_xh)[(row0 + w) * RV_E + RV_U + e] = (d.h_new + k * d.ls_c)[(row0 + p) * RV_U + e];
+      (d.c + k * d.ls_c)[(row0 + w) * RV_U + e] = (d.c_new + k * d.ls_c)[(row0 + p) * RV_U + e];
+    }
   }
 }
 
@@ -599,8 +614,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int idx = tid + ATT_THREADS * i;
-    hr[i] = idx < W * RV_U ? d.h_new[row0 * RV_U + idx] : 0.f;
-    cr[i] = idx < W * RV_U ? d.c_new[row0 * RV_U + idx] : 0.f;
+    hr[i] = idx < W * RV_U ? (d.h_new + (d.depth - 1) * d.ls_c)[row0 * RV_U + idx] : 0.f;
+    cr[i] = idx < W * RV_U ? (d.c_new + (d.depth - 1) * d.ls_c)[row0 * RV_U + idx] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) { const int idx = tid + ATT_THREADS * i; wfr[i] = idx < RV_U * d.V ? d.W_fc[idx] : 0.f; }
@@ -871,7 +886,7 @@ void launch_dec_init(const DecState& d, hipStream_t s) {
   const int n = max(d.B * d.W, d.L);
   hipLaunchKernelGGL(k_dec_init, dim3((n + 255) / 256), dim3(256), 0, s, d);
 }
-void launch_dec_cell(const DecState& d, const float* WcatT, const float* Wtok, const float* bias, int step,
+void launch_dec_cell(const DecState& d, int layer, const float* WcatT, const float* Wtok, const float* bias, int step,
                      hipStream_t s) {
   const int N = d.B * d.W;
   const size_t shm = sizeof(float) * CELL_LDS_FLOATS;
@@ -880,7 +895,7 @@ void launch_dec_cell(const DecState& d, const float* WcatT, const float* Wtok, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     configured = true;
   }
-  hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + CELL_ROWS - 1) / CELL_ROWS), dim3(512), shm, s, d, WcatT, Wtok, bias, step);
+  hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + CELL_ROWS - 1) / CELL_ROWS), dim3(512), shm, s, d, layer, WcatT, Wtok, bias, step);
 }
 template <int W, int TB, int TD>
 static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {

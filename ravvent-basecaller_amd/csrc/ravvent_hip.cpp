@@ -43,7 +43,7 @@ struct RvContext {
   size_t n_w = 0;
   bool loaded = false;
   std::vector<std::vector<LstmW>> enc[2];   // [enc][layer][dir]
-  LstmW dec{};
+  std::vector<LstmW> dec;                   // stacked decoder cells
   float* d_WmemT = nullptr;                 // derived: W_mem^T [128][256]
   int opt_split = 1;                        // concurrent decode sub-slabs (1..4); measured neutral at B=256
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -140,9 +140,12 @@ void bind_weights(RvContext* h) {
       }
     }
   }
-  h->dec.W = p; p += (V + d) * 4 * d;
-  h->dec.U = p; p += d * 4 * d;
-  h->dec.b = p; p += 4 * d;
+  h->dec.assign(c.dec_depth, LstmW{});
+  for (int k = 0; k < c.dec_depth; ++k) {
+    h->dec[k].W = p; p += (k == 0 ? V + d : d) * 4 * d;
+    h->dec[k].U = p; p += d * 4 * d;
+    h->dec[k].b = p; p += 4 * d;
+  }
   h->W_mem = p; p += 2 * u * d;
   h->W_q = p; p += d * d;
   h->v_att = p; p += d;
@@ -236,14 +239,20 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
 }
 
 void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool profiled) {
-  const float* Wcat = h->d_WcatT;
   const bool flash = h->lflash != 0;
+  auto cells = [&](int step, bool prof) {
+    for (int k = 0; k < d.depth; ++k) {
+      const float* WcatT = h->d_WcatT + (size_t)k * RV_G * RV_E;
+      if (prof) { Scope sc(h, "dec_cell"); launch_dec_cell(d, k, WcatT, k == 0 ? h->dec[0].W : nullptr, h->dec[k].b, step, s); }
+      else launch_dec_cell(d, k, WcatT, k == 0 ? h->dec[0].W : nullptr, h->dec[k].b, step, s);
+    }
+  };
   for (int step = 0; step < d.L - 1; ++step) {
     if (profiled) {
-      { Scope sc(h, "dec_cell"); launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s); }
+      cells(step, true);
       { Scope sc(h, "dec_attend"); launch_dec_attend(d, h->d_WmemT, flash, step, s); }
     } else {
-      launch_dec_cell(d, Wcat, h->dec.W, h->dec.b, step, s);
+      cells(step, false);
       launch_dec_attend(d, h->d_WmemT, flash, step, s);
     }
   }
@@ -340,8 +349,10 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     d.step_align = nullptr;
     if (!greedy) d.step_logits = nullptr;
   }
-  HIPCHK(h, hipMemsetAsync(d.xh, 0, sizeof(float) * N * RV_E, s));
-  HIPCHK(h, hipMemsetAsync(d.c, 0, sizeof(float) * N * RV_U, s));
+  for (int k = 0; k < d.depth; ++k) {     // get_initial_state: all zeros (basecaller.py:305)
+    HIPCHK(h, hipMemsetAsync(d.xh + k * d.ls_xh, 0, sizeof(float) * N * RV_E, s));
+    HIPCHK(h, hipMemsetAsync(d.c + k * d.ls_c, 0, sizeof(float) * N * RV_U, s));
+  }
 
   // The slab decodes as `nsplit` independent sub-slabs on concurrent streams (inside one hipGraph):
   // while one sub-slab is in its HBM-bound attention sweep another runs its latency-bound cell /
@@ -448,8 +459,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   const RvConfig& c = *cfg;
   if (c.enc_units != RV_U || c.dec_units != RV_U)
     return fail(nullptr, RV_EUNSUPPORTED, "this build is specialised for enc_units = dec_units = 128 (got %d, %d)", c.enc_units, c.dec_units);
-  if (c.dec_depth != 1)
-    return fail(nullptr, RV_EUNSUPPORTED, "decoder_depth %d not supported yet (1 only)", c.dec_depth);
+  if (c.dec_depth < 1 || c.dec_depth > 4)
+    return fail(nullptr, RV_EUNSUPPORTED, "decoder_depth %d outside [1,4]", c.dec_depth);
   if (c.enc_depth < 1 || c.enc_depth > 8) return fail(nullptr, RV_EINVAL, "encoder_depth %d outside [1,8]", c.enc_depth);
   if (c.vocab < 2 || c.vocab > RV_MAX_VOCAB) return fail(nullptr, RV_EINVAL, "vocab %d outside [2,%d]", c.vocab, RV_MAX_VOCAB);
   if (c.mode < 0 || c.mode > 2 || c.attention < 0 || c.attention > 1) return fail(nullptr, RV_EINVAL, "bad mode/attention");
@@ -476,7 +487,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
-  TRY(dalloc(h, &h->d_WcatT, (size_t)RV_G * RV_E));
+  TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
   TRY(dalloc(h, &h->d_raw, B * Tr));
@@ -499,11 +510,12 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   DecState& d = h->dec_st;
   if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
   if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
-  TRY(dalloc(h, &d.xh, N * RV_E));
+  d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
+  TRY(dalloc(h, &d.xh, c.dec_depth * N * RV_E));
   TRY(dalloc(h, &d.z, N * RV_G));
-  TRY(dalloc(h, &d.c, N * RV_U));
-  TRY(dalloc(h, &d.c_new, N * RV_U));
-  TRY(dalloc(h, &d.h_new, N * RV_U));
+  TRY(dalloc(h, &d.c, c.dec_depth * N * RV_U));
+  TRY(dalloc(h, &d.c_new, c.dec_depth * N * RV_U));
+  TRY(dalloc(h, &d.h_new, c.dec_depth * N * RV_U));
   TRY(dalloc(h, &d.tok, N));
   TRY(dalloc(h, &d.log_probs, N));
   TRY(dalloc(h, &d.finished, N));
@@ -557,13 +569,16 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
   if (n_floats != h->n_w) return fail(h, RV_EINVAL, "weight blob has %zu floats, config needs %zu", n_floats, h->n_w);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpyAsync(h->d_w, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  {   // derived layout for the decoder cell kernel: rows V..V+127 of W_dec followed by U_dec form a
-      // contiguous [256][512] matrix in the blob; the kernel wants it column-major ([512][256]).
-    const size_t off = (size_t)(h->dec.W - h->d_w) + (size_t)h->cfg.vocab * RV_G;
+  {   // derived layout for the decoder cell kernel: the input-kernel rows that multiply a dense input
+      // (rows V.. of W_0; all of W_k for k >= 1) followed by U_k form a contiguous [256][512] matrix in
+      // the blob; the kernel wants it column-major ([512][256]).
     std::vector<float> t((size_t)RV_G * RV_E);
-    for (int k = 0; k < RV_E; ++k)
-      for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
-    HIPCHK(h, hipMemcpy(h->d_WcatT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int l = 0; l < h->cfg.dec_depth; ++l) {
+      const size_t off = (size_t)(h->dec[l].W - h->d_w) + (l == 0 ? (size_t)h->cfg.vocab * RV_G : 0);
+      for (int k = 0; k < RV_E; ++k)
+        for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
+      HIPCHK(h, hipMemcpy(h->d_WcatT + (size_t)l * RV_G * RV_E, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
     std::vector<float> m((size_t)RV_U * RV_E);
     for (int i = 0; i < RV_E; ++i)
