@@ -85,6 +85,17 @@ int rv_beam_search_dev(rv_handle h, const float* d_raw, const float* d_event, in
                        int32_t T_e, int32_t W, int32_t L, int32_t* d_tokens, float* d_scores,
                        int32_t* S_out);
 
+/* Beam search with the callers' post-processing fused on the device (scope row 8f#3):
+ * tokens_to_nuc_sequences (basecaller.py:289-294) and calc_prob_logits_beam_search_scores
+ * (utils.py:123-128) of the best beam, as ravvent_performance_evaluator.py:66-70 consumes them.
+ *   lut[vocab]: token id -> upper-case ASCII letter, 0 for ids the string form drops ('', '^', '$');
+ *   bases [B, L-1] u8: the chunk's letters compacted to the front (zero-filled tail);
+ *   lengths [B] i32: letters per chunk;  probs [B, L-1] f32: exp(score_t - score_{t-1}), score_{-1} = 0
+ *   (the reference pairs a chunk's string with probs[:len(string)]).  Host buffers. */
+int rv_beam_search_calls(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r,
+                         int32_t T_e, int32_t W, int32_t L, const uint8_t* lut, uint8_t* bases,
+                         int32_t* lengths, float* probs, int32_t* S_out);
+
 /* Basecaller.greedy_search_prediction (basecaller.py:317-330): tokens = sample_id [B, L-1],
  * logits = rnn_output [B, L-1, vocab]; columns >= S are pad_token / 0. */
 int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r,

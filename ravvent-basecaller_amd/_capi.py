@@ -25,6 +25,7 @@ SYMBOLS = [
     ("rv_load_weights", c_int32, [c_void_p, c_void_p, c_size_t]),
     ("rv_beam_search", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_beam_search_dev", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
+    ("rv_beam_search_calls", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, _I]),
     ("rv_greedy_search", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_greedy_search_dev", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_set_option", c_int32, [c_void_p, c_char_p, c_int32]),

@@ -220,6 +220,32 @@ class Basecaller:
                           torch.empty(shape2, dtype=torch.float32, device=self.device))
         return cache[key]
 
+    def beam_search_calls(self, input_data, beam_width, max_output_len):
+        """beam_search_prediction + the evaluators' post-processing fused on the device
+        (ravvent_performance_evaluator.py:55,66-70): returns (seqs: list[str], probs: list[np.ndarray])
+        where probs[i] = calc_prob_logits_beam_search_scores(scores)[i][:len(seqs[i])]."""
+        keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
+        if on_dev:   # host-buffer entry point: bring device tensors down (inputs are ~2 KB per chunk)
+            return self.beam_search_calls(tuple(None if k is None else k.cpu().numpy() for k in keep)
+                                          if self.input_data_type == "joint" else
+                                          (keep[0] if keep[0] is not None else keep[1]).cpu().numpy(),
+                                          beam_width, max_output_len)
+        L = _as_int(max_output_len)
+        steps = max(L - 1, 0)
+        lut = np.zeros(8, np.uint8)
+        for idx, word in self.tokenizer.index_word.items():
+            if 0 <= idx < 8 and word not in ("", "^", "$", " "):
+                lut[idx] = ord(word.upper())
+        bases = np.zeros((B, steps), np.uint8); lens = np.zeros(B, np.int32); probs = np.zeros((B, steps), np.float32)
+        S = ctypes.c_int32(0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._lib.rv_beam_search_calls(self._h, pr, pe, B, Tr, Te, int(beam_width), L, p(lut), p(bases),
+                                                   p(lens), p(probs), ctypes.byref(S)), "rv_beam_search_calls")
+        self.last_steps = S.value
+        flat = bases.tobytes()
+        seqs = [flat[i * steps:i * steps + int(n)].decode("ascii") for i, n in enumerate(lens)]
+        return seqs, [probs[i, :int(n)] for i, n in enumerate(lens)]
+
     def tokens_to_nuc_sequences(self, result_tokens):
         """basecaller.py:289-294"""
         if isinstance(result_tokens, torch.Tensor):

@@ -86,6 +86,11 @@ struct DecState {
   float* step_logits;     // [L-1,B,W,V]   (greedy or debug) or nullptr
   float* step_align;      // [L-1,B,W,Tm]  (debug) or nullptr
   int* nfin;              // [L] chunks-finished counter per step
+  // optional fused post-processing of the best beam (basecaller.py:289-294 + utils.py:123-128)
+  uint8_t* call_bases;    // [B,L-1] compacted base letters of tokens_to_nuc_sequences (or nullptr)
+  float* call_probs;      // [B,L-1] exp(score_t - score_{t-1})
+  int* call_len;          // [B] letters per chunk
+  uint8_t lut[RV_MAX_VOCAB];   // token id -> upper-case letter, 0 for tokens the string form drops
   int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

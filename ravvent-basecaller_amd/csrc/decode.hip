@@ -851,9 +851,24 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
     }
   }
   __syncthreads();
-  for (int s = tid; s < steps; s += 64) {
-    tk[s] = s < S ? s_tok[s] : d.pad_token;
-    out2[(size_t)b * steps + s] = s < S ? d.step_scores[((size_t)min(s, So - 1) * d.B + b) * W] : 0.f;
+  // one wave, lane = step (max_output_len <= 64)
+  const int s = tid;
+  const int tokv = s < S ? s_tok[s] : d.pad_token;
+  const float scv = s < S ? d.step_scores[((size_t)min(s, So - 1) * d.B + b) * W] : 0.f;
+  if (s < steps) { tk[s] = tokv; out2[(size_t)b * steps + s] = scv; }
+  if (d.call_bases) {
+    // fused tokens_to_nuc_sequences + calc_prob_logits_beam_search_scores for this chunk
+    const float prev = __shfl_up(scv, 1);
+    const uint8_t ch = (s < S && tokv >= 0 && tokv < RV_MAX_VOCAB) ? d.lut[tokv] : 0;
+    const unsigned long long m = __ballot(ch != 0);
+    const int pos = __popcll(m & ((1ull << s) - 1ull));
+    if (s < steps) {
+      d.call_probs[(size_t)b * steps + s] = s < S ? __expf(scv - (s == 0 ? 0.f : prev)) : 0.f;
+      d.call_bases[(size_t)b * steps + s] = 0;
+    }
+    __syncthreads();
+    if (ch) d.call_bases[(size_t)b * steps + pos] = ch;
+    if (s == 0) d.call_len[b] = __popcll(m);
   }
 }
 

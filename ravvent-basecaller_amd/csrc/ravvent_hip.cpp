@@ -70,6 +70,9 @@ struct RvContext {
   float *pin_raw = nullptr, *pin_ev = nullptr, *pin_out2 = nullptr;
   int32_t* pin_tok = nullptr;
   int* pin_S = nullptr;
+  uint8_t *d_bases = nullptr, *pin_bases = nullptr;
+  float *d_probs = nullptr, *pin_probs = nullptr;
+  int *d_clen = nullptr, *pin_clen = nullptr;
 
   int opt_taps = 0, opt_graph = 1, opt_profile = 0;
   std::map<std::string, ProfEntry> prof;
@@ -258,8 +261,10 @@ void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool pr
   }
 }
 
+struct CallsOut { const uint8_t* lut; uint8_t* bases; int32_t* lengths; float* probs; };
+
 int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W,
-        int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, int32_t* S_out) {
+        int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, int32_t* S_out, const CallsOut* calls = nullptr) {
   if (!h) return RV_EINVAL;
   const RvConfig& c = h->cfg;
   if (!h->loaded) return fail(h, RV_ESTATE, "no weights loaded (call rv_load_weights first)");
@@ -274,7 +279,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if ((use_raw && !raw) || (use_ev && !ev)) return fail(h, RV_EINVAL, "missing input pointer for this mode");
   if (T_r + T_e > 352) return fail(h, RV_EUNSUPPORTED, "attention memory of %d steps exceeds the 352 the decode kernel is built for", T_r + T_e);
   if (L > 64) return fail(h, RV_EUNSUPPORTED, "max_output_len %d exceeds 64", L);
-  if (!S_out || (B > 0 && L > 1 && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
+  if (!S_out || (B > 0 && L > 1 && !calls && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
+  if (calls && (!calls->lut || !calls->bases || !calls->lengths || !calls->probs)) return fail(h, RV_EINVAL, "null calls output pointer");
   HIPCHK(h, hipSetDevice(c.device));
   h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps;
   *S_out = 0;
@@ -333,6 +339,11 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   d.start_token = c.start_token; d.end_token = c.end_token; d.pad_token = c.pad_token;
   d.keys = h->keys; d.values = h->enc_out; d.mask = h->mask;
   d.W_att = h->W_att; d.W_fc = h->W_fc; d.b_fc = h->b_fc; d.W_q = h->W_q; d.v_att = h->v_att;
+  d.call_bases = nullptr; d.call_probs = nullptr; d.call_len = nullptr;
+  if (calls) {
+    d.call_bases = h->d_bases; d.call_probs = h->d_probs; d.call_len = h->d_clen;
+    for (int v = 0; v < RV_MAX_VOCAB; ++v) d.lut[v] = v < V ? calls->lut[v] : 0;
+  }
   const int N = B * d.W;
   if (h->opt_taps) {
     const size_t need = (size_t)steps * N * Tm;
@@ -369,6 +380,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     DecState& p = part[g];
     p = d;
     p.part = g; p.B = (int)(b1 - b0);
+    if (p.call_bases) { p.call_bases += b0 * steps; p.call_probs += b0 * steps; p.call_len += b0; }
     p.keys += b0 * Tm * RV_U; p.values += b0 * Tm * RV_E; p.mask += b0 * Tm;
     p.xh += b0 * Wd * RV_E; p.z += b0 * Wd * RV_G;
     p.c += b0 * Wd * RV_U; p.c_new += b0 * Wd * RV_U; p.h_new += b0 * Wd * RV_U;
@@ -416,8 +428,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     if (rc != RV_OK) return rc;
   }
 
-  int32_t* tk = dev_out ? tokens : h->out_tokens;
-  float* o2 = dev_out ? out2 : h->out2;
+  int32_t* tk = (dev_out && tokens) ? tokens : h->out_tokens;
+  float* o2 = (dev_out && out2) ? out2 : h->out2;
   {
     Scope sc(h, "dec_finalize");
     launch_dec_reduce_steps(parts, s);
@@ -427,16 +439,26 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
   }
   HIPCHK(h, hipMemcpyAsync(h->pin_S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-  if (!dev_out) {
+  if (!dev_out && tokens) {
     HIPCHK(h, hipMemcpyAsync(h->pin_tok, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
+  }
+  if (calls) {
+    HIPCHK(h, hipMemcpyAsync(h->pin_bases, h->d_bases, (size_t)B * steps, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_probs, h->d_probs, sizeof(float) * B * steps, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_clen, h->d_clen, sizeof(int) * B, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
   const int S = *h->pin_S;
-  if (!dev_out) {
+  if (!dev_out && tokens) {
     memcpy(tokens, h->pin_tok, sizeof(int32_t) * B * steps);
     memcpy(out2, h->pin_out2, sizeof(float) * B * steps * (greedy ? V : 1));
+  }
+  if (calls) {
+    memcpy(calls->bases, h->pin_bases, (size_t)B * steps);
+    memcpy(calls->probs, h->pin_probs, sizeof(float) * B * steps);
+    memcpy(calls->lengths, h->pin_clen, sizeof(int) * B);
   }
   drain_profile(h);
   *S_out = S;
@@ -539,6 +561,12 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   HIPTRY(hipHostMalloc((void**)&h->pin_tok, B * L * sizeof(int32_t), hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_out2, B * L * V * sizeof(float), hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocDefault));
+  TRY(dalloc(h, &h->d_bases, B * L));
+  TRY(dalloc(h, &h->d_probs, B * L));
+  TRY(dalloc(h, &h->d_clen, B));
+  HIPTRY(hipHostMalloc((void**)&h->pin_bases, B * L, hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_probs, B * L * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_clen, B * sizeof(int), hipHostMallocDefault));
 #undef TRY
 #undef HIPTRY
   *out = h;
@@ -555,7 +583,7 @@ void rv_destroy(rv_handle h) {
   for (int g = 0; g < 3; ++g) { if (h->side[g]) hipStreamDestroy(h->side[g]); if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->step_align) hipFree(h->step_align);
-  for (void* p : {(void*)h->pin_raw, (void*)h->pin_ev, (void*)h->pin_tok, (void*)h->pin_out2, (void*)h->pin_S}) if (p) hipHostFree(p);
+  for (void* p : {(void*)h->pin_raw, (void*)h->pin_ev, (void*)h->pin_tok, (void*)h->pin_out2, (void*)h->pin_S, (void*)h->pin_bases, (void*)h->pin_probs, (void*)h->pin_clen}) if (p) hipHostFree(p);
   for (void* p : h->allocs) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -597,6 +625,12 @@ int rv_beam_search(rv_handle h, const float* raw, const float* event, int32_t B,
 int rv_beam_search_dev(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
                        int32_t W, int32_t L, int32_t* tokens, float* scores, int32_t* S_out) {
   return run(h, raw, event, true, B, T_r, T_e, W, L, false, tokens, scores, true, S_out);
+}
+int rv_beam_search_calls(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                         int32_t W, int32_t L, const uint8_t* lut, uint8_t* bases, int32_t* lengths, float* probs,
+                         int32_t* S_out) {
+  const CallsOut c{lut, bases, lengths, probs};
+  return run(h, raw, event, false, B, T_r, T_e, W, L, false, nullptr, nullptr, false, S_out, &c);
 }
 int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
                      int32_t L, int32_t* tokens, float* logits, int32_t* S_out) {

@@ -16,9 +16,11 @@ from . import utils
 
 
 class PerformanceEvaluator:
-    def __init__(self, basecaller, stride: int = 6):
+    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False):
         self.basecaller = basecaller
         self.stride = stride           # ravvent_performance_evaluator.py:16
+        # True: strings + per-base probabilities come straight from the device (rv_beam_search_calls)
+        self.fused_postprocessing = fused_postprocessing
 
     @staticmethod
     def _split_into_chunks(arr, def_chunk_size):
@@ -63,6 +65,12 @@ class PerformanceEvaluator:
         for data in data_chunks:
             start = timer()
             input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
+            if self.fused_postprocessing:
+                seqs, probs = self.basecaller.beam_search_calls(input_data, beam_width=beam_width,
+                                                                max_output_len=target_data.shape[1])
+                t_predicting += timer() - start
+                nuc_preds.extend((seq, list(pr)) for seq, pr in zip(seqs, probs))
+                continue
             pred_tokens, beam_scores = self.basecaller.beam_search_prediction(
                 input_data, beam_width=beam_width, max_output_len=target_data.shape[1])
             t_predicting += timer() - start
