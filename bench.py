@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real path) | gloo (control-flow rehearsal: ranks may share a GPU, the gather goes through host memory)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-kernel event pass over the decode loop")
     ap.add_argument("--cpu-sample", type=int, default=0, help="chunks for the CPU baseline (0 = size to ~12 s)")
     args = ap.parse_args()
@@ -101,10 +102,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.dist_backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     B, T_r, T_e, W, L = args.batch, args.raw_len, args.event_len, args.beam, args.max_output_len
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", rv.data_loader.INPUT_PADDING,
@@ -125,7 +131,11 @@ def main():
             S = tok.shape[1]
             packed[:, :S] = tok
             packed[:, L - 1:L - 1 + S] = sc.view(torch.int32)
-            dist.all_gather_into_tensor(gathered, packed)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(gathered, packed)
+            else:
+                g_cpu = torch.empty(gathered.shape, dtype=gathered.dtype)
+                dist.all_gather_into_tensor(g_cpu, packed.cpu())
         return tok, sc
 
     def fence():
@@ -151,7 +161,7 @@ def main():
     gc.enable()
     S = int(tok.shape[1])
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = bc.profile()
@@ -166,8 +176,8 @@ def main():
         if not args.no_kernel_pass:
             bc.set_option("profile", 2)
             bc.reset_profile()
-            for _ in range(3):
-                step()
+            for _ in range(3):     # local decode only: no collective here (this block runs on rank 0 alone)
+                bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
             dec = {k: v for k, v in bc.profile().items() if k.startswith("dec_") and k != "dec_finalize"}
             bc.set_option("profile", 1)
         # time per slab of every kernel name (graph replaced by its members when available)
