@@ -107,6 +107,8 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "use_graph"  (0/1: replay the decode loop from a captured hipGraph),
  *          "decode_split" (1..4, default 1: beam-search decode of one slab runs as that many
  *                       concurrent sub-slabs; results are identical),
+ *          "attend_threads" (0 auto | 256 | 512: workgroup size of the single-pass attend; auto uses
+ *                       256 (two workgroups per CU) for slabs larger than the CU count),
  *          "flash_attend" (0/1, default 1: single-pass Luong attention over values only;
  *                       0 = two-pass keys-then-values dataflow of the reference),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around

@@ -92,6 +92,7 @@ struct DecState {
   int* call_len;          // [B] letters per chunk
   uint8_t lut[RV_MAX_VOCAB];   // token id -> upper-case letter, 0 for tokens the string form drops
   int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
+  int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)

@@ -15,6 +15,7 @@
 #include "common.h"
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -217,25 +218,27 @@ struct AttShared {
 // Dynamic LDS carve-up (floats), shared with the host-side size computation.
 struct AttLds {
   int q, pq, sc, al, part, hcT, att, lg, fold, total;
-  __host__ __device__ AttLds(int W, int TmP, bool flash) {
+  __host__ __device__ AttLds(int W, int TmP, bool flash, int NT = 512) {
+    const int NW = NT / 64;                     // waves per workgroup
     int o = 0;
     q = o; o += W * RV_U;
     pq = o; o += flash ? W * RV_E : W * RV_U;   // Bahdanau processed query [W][128] / flash q' [W][256]
-    sc = o; o += flash ? 32 * WB * 2 : W * TmP; // two-pass: scores [W][TmP]; flash: per-stream (max, sum) [32][WB][2]
+    sc = o; o += flash ? (NT / 16) * WB * 2 : W * TmP; // two-pass: scores [W][TmP]; flash: per-stream (max, sum) [NT/16][WB][2]
     al = o; o += flash ? 2 * WB : TmP * WB;     // two-pass: alignments [TmP][WB]; flash: merged (max, 1/sum)
-    part = o; o += 8 * W * RV_E;                // partial sums [8][W][256] (also [16][W][128], [4][W][128])
+    part = o; o += NW * W * RV_E;               // partial sums [NW][W][256] (also [2 NW][W][128])
     hcT = o; o += (RV_U + RV_E) * WB;           // [h ; context] k-major, beam-minor
     att = o; o += W * RV_U;
     lg = o; o += WB * RV_MAX_VOCAB;
-    fold = o; o += flash ? 8 * W * 4 * 32 * 4 : 0;   // flash: wave-private fold slabs [8][W*4][32] float4
+    fold = o; o += flash ? NW * W * 4 * (NT == 512 ? 32 : 16) * 4 : 0;  // flash: wave-private fold slabs [NW][W*4][32|16] float4
     total = o;
   }
 };
 
 // ---- phase A: one round of small loads -> LDS: query = cell output h of every beam (also rows
 // 0..127 of hcT), the new cell states, the beam bookkeeping and the output layer.
-template <int W>
+template <int W, int NT>
 __device__ __forceinline__ void att_prologue(const DecState& d, AttShared& S, float* q, float* hcT, size_t row0, int tid) {
+  constexpr int ATT_THREADS = NT;
   const int V = d.V;
   const float* hn_top = d.h_new + (d.depth - 1) * d.ls_c;
   const float* cn_top = d.c_new + (d.depth - 1) * d.ls_c;
@@ -256,32 +259,38 @@ __device__ __forceinline__ void att_prologue(const DecState& d, AttShared& S, fl
 
 // ---- phases E-H: attention layer, output layer, sampler / beam step, parent-gather of the state.
 // Expects hcT = [h ; context] complete and a barrier behind it.
-template <int W>
+template <int W, int NT>
 __device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const float* q, const float* hcT, float* part,
                                          float* att, float* lg, int b, int step, int tid) {
+  constexpr int ATT_THREADS = NT;
+  constexpr int NKG = NT / 32;              // K-groups of the attention layer: 16 x 24 rows (NT=512) / 8 x 48 (NT=256)
+  constexpr int KPG = 384 / NKG;
   const int V = d.V;
   const size_t row0 = (size_t)b * W;
   // E: attention = [h ; context] . W_att   (Dense, no bias, no activation)
-  //    thread = (4 output columns, 1 of 16 K-groups of 24 rows); 24 float4 weight loads in flight
+  //    thread = (4 output columns, 1 of NKG K-groups of KPG rows); 24 float4 weight loads in flight
   {
     const int d4 = tid & 31, kg = tid >> 5;
-    float4 wv[24];
-    const float* wa = d.W_att + (size_t)(24 * kg) * RV_U + 4 * d4;
-#pragma unroll
-    for (int u = 0; u < 24; ++u) wv[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
-    __builtin_amdgcn_sched_barrier(0);
     f2 acc[W][2];
 #pragma unroll
     for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
 #pragma unroll
-    for (int u = 0; u < 24; ++u) {
-      float hv[WB];
-      *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + u) * WB]);
-      if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + u) * WB + 4]);
+    for (int k0 = 0; k0 < KPG; k0 += 24) {
+      float4 wv[24];
+      const float* wa = d.W_att + (size_t)(KPG * kg + k0) * RV_U + 4 * d4;
 #pragma unroll
-      for (int w = 0; w < W; ++w) {
-        acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].x, wv[u].y}, acc[w][0]);
-        acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].z, wv[u].w}, acc[w][1]);
+      for (int u = 0; u < 24; ++u) wv[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 24; ++u) {
+        float hv[WB];
+        *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(KPG * kg + k0 + u) * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(KPG * kg + k0 + u) * WB + 4]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].x, wv[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wv[u].z, wv[u].w}, acc[w][1]);
+        }
       }
     }
 #pragma unroll
@@ -290,11 +299,11 @@ __device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const 
           make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
   }
   __syncthreads();
-  for (int i = tid; i < W * RV_U; i += ATT_THREADS) {      // fixed-order reduction of the 16 partials
+  for (int i = tid; i < W * RV_U; i += ATT_THREADS) {      // fixed-order reduction of the partials
     const int w = i >> 7, col = i & 127;
     float s0 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+    for (int g = 0; g < NKG; ++g) s0 += part[(g * W + w) * RV_U + col];
     att[i] = s0;
   }
   __syncthreads();
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
     return;
   }
   const size_t row0 = (size_t)b * W;
-  att_prologue<W>(d, S, q, hcT, row0, tid);
+  att_prologue<W, 512>(d, S, q, hcT, row0, tid);
   __syncthreads();
   if (d.attention == 1) {   // Bahdanau: processed query = q . W_q ; thread = (column, K quarter)
     const int jj = tid & 127, kq = tid >> 7;
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
     hcT[(RV_U + col) * WB + w] = s;
   }
   __syncthreads();
-  att_tail<W>(d, S, q, hcT, part, att, lg, b, step, tid);
+  att_tail<W, 512>(d, S, q, hcT, part, att, lg, b, step, tid);
 }
 
 // =====================================================================================
@@ -569,11 +578,15 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend(DecState d, int step
 // t = stream, stream+32, ... with a 3-deep register prefetch, keep their own running
 // (max, sum, context[W][256]) and are merged once at the end in a fixed order.
 // q' carries log2(e) so the exponentials are bare v_exp_f32.
-template <int W>
-__global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, const float* __restrict__ WmemT, int step) {
+// NT = 512: 32 streams, one workgroup per CU (slabs up to the CU count).  NT = 256: 16 streams, 71 KB of LDS
+// and 196 VGPRs -> TWO workgroups per CU, so one chunk's latency-bound phases (cell-output fetch, q',
+// attention layer, beam step) run under the other chunk's HBM-bound sweep (slabs larger than the CU count).
+template <int W, int NT>
+__global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float* __restrict__ WmemT, int step) {
+  constexpr int ATT_THREADS = NT, NW = NT / 64, NS = NT / 16;
   extern __shared__ __align__(16) float dsm[];
   const int Tm = d.Tm;
-  const AttLds L(W, 0, true);
+  const AttLds L(W, 0, true, NT);
   float* q = dsm + L.q;        // [W][128]
   float* qp = dsm + L.pq;      // [W][256]  q' * log2(e)
   float* ml = dsm + L.sc;      // [32][WB][2] per-stream (max, sum)
@@ -592,15 +605,15 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
   }
   const size_t row0 = (size_t)b * W;
   RV_STAMP(d, step, 0);
-  const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4;   // sid: stream 0..31
+  const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4;   // sid: stream 0..NS-1
   constexpr int PD = 3;                                                       // prefetch depth (iterations)
   const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * sub;
   const uint8_t* mrow = d.mask + (size_t)b * Tm;
-  const int nit = (Tm + 31) >> 5;
+  const int nit = (Tm + NS - 1) / NS;
   float4 pv[PD][4];
   uint8_t pm[PD];
   auto issue = [&](int slot, int it) {
-    const int t = min(sid + 32 * it, Tm - 1);
+    const int t = min(sid + NS * it, Tm - 1);
     const float* p = vbase + (size_t)t * RV_E;
 #pragma unroll
     for (int m = 0; m < 4; ++m) pv[slot][m] = *reinterpret_cast<const float4*>(p + 64 * m);
@@ -609,7 +622,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
   // small loads first, INTO REGISTERS (vmcnt retires in issue order), then the stream, then the LDS
   // writes: the prologue waits one short round trip while the value rows are already in flight.
   constexpr int NC = (W * RV_U + ATT_THREADS - 1) / ATT_THREADS;
-  float hr[NC], cr[NC], wfr[2];
+  constexpr int NWF = (RV_U * RV_MAX_VOCAB + ATT_THREADS - 1) / ATT_THREADS;   // W_fc staging slots per thread
+  float hr[NC], cr[NC], wfr[NWF];
   int sm0 = 0, sm2 = 0; float sm1 = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
     cr[i] = idx < W * RV_U ? (d.c_new + (d.depth - 1) * d.ls_c)[row0 * RV_U + idx] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const int idx = tid + ATT_THREADS * i; wfr[i] = idx < RV_U * d.V ? d.W_fc[idx] : 0.f; }
+  for (int i = 0; i < NWF; ++i) { const int idx = tid + ATT_THREADS * i; wfr[i] = idx < RV_U * d.V ? d.W_fc[idx] : 0.f; }
   const float bfr = tid < d.V ? d.b_fc[tid] : 0.f;
   if (tid < W) { sm0 = d.finished[row0 + tid]; sm1 = d.log_probs[row0 + tid]; sm2 = d.lengths[row0 + tid]; }
   __builtin_amdgcn_sched_barrier(0);
@@ -631,30 +645,34 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
     if (idx < W * RV_U) { q[idx] = hr[i]; hcT[(idx & 127) * WB + (idx >> 7)] = hr[i]; S.cnew[idx] = cr[i]; }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const int idx = tid + ATT_THREADS * i; if (idx < RV_U * d.V) S.wfc[idx] = wfr[i]; }
+  for (int i = 0; i < NWF; ++i) { const int idx = tid + ATT_THREADS * i; if (idx < RV_U * d.V) S.wfc[idx] = wfr[i]; }
   if (tid < d.V) S.wfc[RV_U * d.V + tid] = bfr;
   if (tid < W) { S.fin[tid] = sm0; S.lprob[tid] = sm1; S.len[tid] = sm2; }
   __syncthreads();
   RV_STAMP(d, step, 1);
-  // q' = W_mem . q (times log2 e): thread = (4 columns, 1 of 8 j-groups of 16), W_memT is [128][256]
+  // q' = W_mem . q (times log2 e): thread = (4 columns, 1 of NW j-groups), W_memT is [128][256]
   {
+    constexpr int JPG = RV_U / NW;                      // rows of W_memT per j-group (16 or 32)
     const int c4 = tid & 63, jg = tid >> 6;
-    float4 wm[16];
-    const float* wp = WmemT + (size_t)(16 * jg) * RV_E + 4 * c4;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
     f2 acc[W][2];
 #pragma unroll
     for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      float hv[WB];
-      *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + u) * WB]);
-      if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + u) * WB + 4]);
+    for (int j0 = 0; j0 < JPG; j0 += 16) {
+      float4 wm[16];
+      const float* wp = WmemT + (size_t)(JPG * jg + j0) * RV_E + 4 * c4;
 #pragma unroll
-      for (int w = 0; w < W; ++w) {
-        acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].x, wm[u].y}, acc[w][0]);
-        acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
+      for (int u = 0; u < 16; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        float hv[WB];
+        *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(JPG * jg + j0 + u) * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(JPG * jg + j0 + u) * WB + 4]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].x, wm[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
+        }
       }
     }
 #pragma unroll
@@ -667,7 +685,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
     const int w = i >> 8, col = i & 255;
     float s0 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+    for (int g = 0; g < NW; ++g) s0 += part[(g * W + w) * RV_E + col];
     qp[i] = s0 * LOG2E;
   }
   __syncthreads();
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
       if (it < nit) {                                   // wave-uniform
         asm volatile("" ::: "memory");                  // keep the q' LDS reads inside the loop (LICM would
                                                         // pin 16*W registers and spill; spill traffic drains vmcnt)
-        const int t = sid + 32 * it;
+        const int t = sid + NS * it;
         const bool live = t < Tm && pm[k] != 0;
         f2 v[8];
 #pragma unroll
@@ -727,80 +745,86 @@ __global__ __launch_bounds__(ATT_THREADS) void k_dec_attend_flash(DecState d, co
     }
   }
   RV_STAMP(d, step, 3);
-  // ---- merge the 32 streams: global max / sum per beam, then a fixed-order sum of rescaled contexts
+  // ---- merge the NS streams: global max / sum per beam, then a fixed-order sum of rescaled contexts
   if (sub < W) { ml[(sid * WB + sub) * 2] = M; ml[(sid * WB + sub) * 2 + 1] = l; }
   __syncthreads();
-  if (wv < W) {                          // wave w merges beam w: lane = stream
-    const float Ms = lane < 32 ? ml[(lane * WB + wv) * 2] : -INFINITY;
-    const float ls = lane < 32 ? ml[(lane * WB + wv) * 2 + 1] : 0.f;
+  for (int w = wv; w < W; w += NW) {     // a wave merges beam w: lane = stream
+    const float Ms = lane < NS ? ml[(lane * WB + w) * 2] : -INFINITY;
+    const float ls = lane < NS ? ml[(lane * WB + w) * 2 + 1] : 0.f;
     const float Mg = wave_max_fast(Ms);
     const float lsum = wave_sum_fast(Ms == -INFINITY ? 0.f : ls * exp2f(Ms - Mg));
     if (lane == 0) {
-      mg[wv * 2] = Mg;
-      mg[wv * 2 + 1] = 1.0f / lsum;      // all-masked chunk: 1/0 -> inf, context NaN like the reference's softmax
+      mg[w * 2] = Mg;
+      mg[w * 2 + 1] = 1.0f / lsum;       // all-masked chunk: 1/0 -> inf, context NaN like the reference's softmax
     }
   }
   __syncthreads();
   {
     const float Mg = sub < W ? mg[sub * 2] : 0.f;
     const float fs = M == -INFINITY ? 0.f : exp2f(M - Mg);          // this stream's weight for beam `sub`
-    // fold the wave's 4 streams (rows hold the same columns) through a wave-private LDS slab:
-    // rows 2,3 -> rows 0,1, then row 1 -> row 0.  Same-wave exchange: no workgroup barrier.
-    float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (W * 4 * 32 * 4));
+    // fold the wave's 4 streams (its 4 DPP rows hold the same columns) through a wave-private 16-lane LDS
+    // slab: row 3 -> row 1, row 2 -> row 0, row 1 -> row 0.  Same-wave exchange: no workgroup barrier.
+    constexpr int SL = NT == 512 ? 32 : 16;             // slab lanes: 2-step fold where LDS allows, else 3-step
+    float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (W * 4 * SL * 4));
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       const float f = row_bcast(fs, w);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[w][i] = acc[w][i] * f2{f, f};
     }
-    if (lane >= 32) {
+    const int row = lane >> 4;
+    // both schedules add (row0 + row2) + (row1 + row3): identical results
+    constexpr int NSTEP = NT == 512 ? 2 : 3;
+#pragma unroll
+    for (int stepf = 0; stepf < NSTEP; ++stepf) {
+      bool is_src, is_dst; int sl;
+      if (NT == 512) {       // rows {2,3} -> {0,1}, then row 1 -> row 0
+        is_src = stepf == 0 ? lane >= 32 : row == 1;
+        is_dst = stepf == 0 ? lane < 32 : row == 0;
+        sl = stepf == 0 ? (lane & 31) : sub;
+      } else {               // row 3 -> 1, row 2 -> 0, row 1 -> 0
+        const int src = stepf == 0 ? 3 : (stepf == 1 ? 2 : 1), dst = stepf == 0 ? 1 : 0;
+        is_src = row == src; is_dst = row == dst; sl = sub;
+      }
+      if (is_src) {
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            slab[(w * 4 + m) * SL + sl] = make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's LDS writes have landed
+      if (is_dst) {
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float4 o = slab[(w * 4 + m) * SL + sl];
+            acc[w][2 * m] += f2{o.x, o.y}; acc[w][2 * m + 1] += f2{o.z, o.w};
+          }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    if (row == 0) {
 #pragma unroll
       for (int w = 0; w < W; ++w)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          slab[(w * 4 + m) * 32 + (lane - 32)] = make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the wave's LDS writes have landed
-    if (lane < 32) {
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float4 o = slab[(w * 4 + m) * 32 + lane];
-          acc[w][2 * m] += f2{o.x, o.y}; acc[w][2 * m + 1] += f2{o.z, o.w};
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (lane >= 16 && lane < 32) {
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          slab[(w * 4 + m) * 32 + (lane - 16)] = make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (lane < 16) {
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float4 o = slab[(w * 4 + m) * 32 + lane];
           *reinterpret_cast<float4*>(&part[(wv * W + w) * RV_E + 4 * sub + 64 * m]) =
-              make_float4(acc[w][2 * m].x + o.x, acc[w][2 * m].y + o.y, acc[w][2 * m + 1].x + o.z, acc[w][2 * m + 1].y + o.w);
-        }
+              make_float4(acc[w][2 * m].x, acc[w][2 * m].y, acc[w][2 * m + 1].x, acc[w][2 * m + 1].y);
     }
   }
   __syncthreads();
-  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction over the 8 waves
+  for (int i = tid; i < W * RV_E; i += ATT_THREADS) {     // fixed-order reduction over the waves
     const int w = i >> 8, col = i & 255;
     float s0 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+    for (int g = 0; g < NW; ++g) s0 += part[(g * W + w) * RV_E + col];
     hcT[(RV_U + col) * WB + w] = s0 * mg[w * 2 + 1];
   }
   __syncthreads();
   RV_STAMP(d, step, 4);
-  att_tail<W>(d, S, q, hcT, part, att, lg, b, step, tid);
+  att_tail<W, NT>(d, S, q, hcT, part, att, lg, b, step, tid);
   RV_STAMP(d, step, 8);
 }
 
@@ -926,13 +950,23 @@ static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {
 template <int W>
 static void launch_attend_w(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s) {
   if (flash) {
-    const size_t shm = sizeof(float) * AttLds(W, 0, true).total;
-    static bool configured = false;
-    if (!configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      configured = true;
+    if (d.attend_threads ? d.attend_threads == 256 : d.B > 320) {     // more chunks than CUs: two 256-thread workgroups per CU overlap each other's phases
+      const size_t shm = sizeof(float) * AttLds(W, 0, true, 256).total;
+      static bool configured = false;
+      if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        configured = true;
+      }
+      hipLaunchKernelGGL((k_dec_attend_flash<W, 256>), dim3(d.B), dim3(256), shm, s, d, WmemT, step);
+    } else {
+      const size_t shm = sizeof(float) * AttLds(W, 0, true, 512).total;
+      static bool configured = false;
+      if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        configured = true;
+      }
+      hipLaunchKernelGGL((k_dec_attend_flash<W, 512>), dim3(d.B), dim3(512), shm, s, d, WmemT, step);
     }
-    hipLaunchKernelGGL((k_dec_attend_flash<W>), dim3(d.B), dim3(ATT_THREADS), shm, s, d, WmemT, step);
     return;
   }
   if (d.Tm <= 64) launch_attend_wt<W, 2, 8>(d, step, s);

@@ -48,6 +48,7 @@ struct RvContext {
   int opt_split = 1;                        // concurrent decode sub-slabs (1..4); measured neutral at B=256
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int opt_att_nt = 0;
   int opt_side_ev = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0;
@@ -337,6 +338,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   d.B = B; d.W = greedy ? 1 : W; d.Tm = Tm; d.V = V; d.L = L;
   d.greedy = greedy; d.attention = c.attention;
   d.start_token = c.start_token; d.end_token = c.end_token; d.pad_token = c.pad_token;
+  d.attend_threads = h->opt_att_nt;
   d.keys = h->keys; d.values = h->enc_out; d.mask = h->mask;
   d.W_att = h->W_att; d.W_fc = h->W_fc; d.b_fc = h->b_fc; d.W_q = h->W_q; d.v_att = h->v_att;
   d.call_bases = nullptr; d.call_probs = nullptr; d.call_len = nullptr;
@@ -405,7 +407,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     return RV_OK;
   };
   if (h->opt_graph && h->opt_profile != 2) {
-    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash, nsplit};
+    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -647,6 +649,10 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
+  else if (!strcmp(key, "attend_threads")) {
+    if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");
+    h->opt_att_nt = value;
+  }
   else if (!strcmp(key, "decode_split")) h->opt_split = value < 1 ? 1 : (value > 4 ? 4 : value);
   else if (!strcmp(key, "profile")) h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value);
   else return fail(h, RV_EINVAL, "unknown option '%s'", key);
