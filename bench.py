@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attend-threads", type=int, default=0, help="0 auto | 256 | 512 (library option attend_threads)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real path) | gloo (control-flow rehearsal: ranks may share a GPU, the gather goes through host memory)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-kernel event pass over the decode loop")
     ap.add_argument("--cpu-sample", type=int, default=0, help="chunks for the CPU baseline (0 = size to ~12 s)")
@@ -118,6 +119,8 @@ def main():
                        beam_width=W, device=local, max_batch=B, max_raw_len=T_r, max_event_len=T_e,
                        max_output_len=L)
     flat = bc.init_random_weights(seed=22)            # Keras-default initialisers, seed as ravvent.py:9
+    if args.attend_threads:
+        bc.set_option("attend_threads", args.attend_threads)
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=rank)
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
     packed = gathered = None
