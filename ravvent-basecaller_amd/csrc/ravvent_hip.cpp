@@ -410,6 +410,10 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
+      if (h->graphs.size() >= 32) {      // bound the cache (callers with ever-changing slab shapes)
+        for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+      }
       hipGraph_t graph = nullptr;
       HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       const int rc = enqueue(false);
