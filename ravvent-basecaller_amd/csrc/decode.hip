@@ -261,12 +261,13 @@ __device__ __forceinline__ void att_prologue(const DecState& d, AttShared& S, fl
 // Expects hcT = [h ; context] complete and a barrier behind it.
 template <int W, int NT>
 __device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const float* q, const float* hcT, float* part,
-                                         float* att, float* lg, int b, int step, int tid) {
+                                         float* att, float* lg, int b, int step, int tid, bool all_fin = false) {
   constexpr int ATT_THREADS = NT;
   constexpr int NKG = NT / 32;              // K-groups of the attention layer: 16 x 24 rows (NT=512) / 8 x 48 (NT=256)
   constexpr int KPG = 384 / NKG;
   const int V = d.V;
   const size_t row0 = (size_t)b * W;
+  if (!all_fin) {     // a chunk whose beams are all finished needs no logits (see the caller)
   // E: attention = [h ; context] . W_att   (Dense, no bias, no activation)
   //    thread = (4 output columns, 1 of NKG K-groups of KPG rows); 24 float4 weight loads in flight
   {
@@ -328,6 +329,7 @@ __device__ __forceinline__ void att_tail(const DecState& d, AttShared& S, const 
   __syncthreads();
   RV_STAMP(d, step, 6);
   if (d.dbg_stop == 6) return;
+  }   // !all_fin
 
   // G: sampler / beam step, wave 0: lane = candidate (beam w, token v), W*V <= 64
   if (tid < 64) {
@@ -650,6 +652,17 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
   if (tid < W) { S.fin[tid] = sm0; S.lprob[tid] = sm1; S.len[tid] = sm2; }
   __syncthreads();
   RV_STAMP(d, step, 1);
+  // A chunk whose W beams are ALL finished contributes only (beam, end-token) candidates at unchanged
+  // scores (finished rows are replaced by [min.., 0 at '^']): its logits are never read,
+  // so the cell output, attention and output layer are skipped and only the beam bookkeeping runs.  The
+  // states written for such a chunk are never used for an output again.  (Not under debug taps, which
+  // record logits of finished beams, and not for greedy decoding, whose rows keep sampling.)
+  bool all_fin = !d.greedy && !d.step_logits && !d.step_align;
+  for (int w = 0; w < W; ++w) all_fin = all_fin && S.fin[w] != 0;
+  if (all_fin) {
+    att_tail<W, NT>(d, S, q, hcT, part, att, lg, b, step, tid, true);
+    return;
+  }
   // q' = W_mem . q (times log2 e): thread = (4 columns, 1 of NW j-groups), W_memT is [128][256]
   {
     constexpr int JPG = RV_U / NW;                      // rows of W_memT per j-group (16 or 32)
