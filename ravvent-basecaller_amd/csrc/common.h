@@ -97,6 +97,7 @@ struct DecState {
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)
 };
+void configure_decode_kernels();   // per-device dynamic-LDS opt-in; call after hipSetDevice
 void launch_dec_init(const DecState& d, hipStream_t s);
 // layer: which stacked cell; Wtok (one-hot embedding rows) is non-null for layer 0 only
 void launch_dec_cell(const DecState& d, int layer, const float* WcatT /*[512,256] = ([W_in;U])^T*/, const float* Wtok /*[V,512]*/,

@@ -942,22 +942,12 @@ void launch_dec_cell(const DecState& d, int layer, const float* WcatT, const flo
                      hipStream_t s) {
   const int N = d.B * d.W;
   const size_t shm = sizeof(float) * CELL_LDS_FLOATS;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    configured = true;
-  }
   hipLaunchKernelGGL(k_dec_cell, dim3(RV_U / 16, (N + CELL_ROWS - 1) / CELL_ROWS), dim3(512), shm, s, d, layer, WcatT, Wtok, bias, step);
 }
 template <int W, int TB, int TD>
 static void launch_attend_wt(const DecState& d, int step, hipStream_t s) {
   const int TmP = (d.Tm + 3) & ~3;
   const size_t shm = sizeof(float) * AttLds(W, TmP, false).total;
-  static size_t configured = 48 * 1024;
-  if (shm > configured) {   // large dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend<W, TB, TD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    configured = shm;
-  }
   hipLaunchKernelGGL((k_dec_attend<W, TB, TD>), dim3(d.B), dim3(ATT_THREADS), shm, s, d, step);
 }
 template <int W>
@@ -965,19 +955,9 @@ static void launch_attend_w(const DecState& d, const float* WmemT, bool flash, i
   if (flash) {
     if (d.attend_threads ? d.attend_threads == 256 : d.B > 320) {     // more chunks than CUs: two 256-thread workgroups per CU overlap each other's phases
       const size_t shm = sizeof(float) * AttLds(W, 0, true, 256).total;
-      static bool configured = false;
-      if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        configured = true;
-      }
       hipLaunchKernelGGL((k_dec_attend_flash<W, 256>), dim3(d.B), dim3(256), shm, s, d, WmemT, step);
     } else {
       const size_t shm = sizeof(float) * AttLds(W, 0, true, 512).total;
-      static bool configured = false;
-      if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        configured = true;
-      }
       hipLaunchKernelGGL((k_dec_attend_flash<W, 512>), dim3(d.B), dim3(512), shm, s, d, WmemT, step);
     }
     return;
@@ -998,6 +978,27 @@ void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int st
     default: launch_attend_w<8>(d, WmemT, flash, step, s); break;
   }
 }
+// Kernels that use more than the default dynamic-LDS limit opt in once per device (called by rv_create
+// after hipSetDevice): sized for the largest shapes the library accepts (T_m <= 352).
+template <int W>
+static void configure_w() {
+  constexpr int cap = 160 * 1024 - 10 * 1024;    // leave room for the kernels' static LDS
+  auto opt = [](const void* f, size_t bytes) {
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < (size_t)cap ? bytes : (size_t)cap));
+  };
+  opt(reinterpret_cast<const void*>(&k_dec_attend<W, 2, 8>), sizeof(float) * AttLds(W, 64, false).total);
+  opt(reinterpret_cast<const void*>(&k_dec_attend<W, 7, 28>), sizeof(float) * AttLds(W, 224, false).total);
+  opt(reinterpret_cast<const void*>(&k_dec_attend<W, 11, 44>), sizeof(float) * AttLds(W, 352, false).total);
+  opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), sizeof(float) * AttLds(W, 0, true, 256).total);
+  opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), sizeof(float) * AttLds(W, 0, true, 512).total);
+}
+void configure_decode_kernels() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * CELL_LDS_FLOATS));
+  configure_w<1>(); configure_w<2>(); configure_w<3>(); configure_w<4>();
+  configure_w<5>(); configure_w<6>(); configure_w<7>(); configure_w<8>();
+}
+
 void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s) {
   hipLaunchKernelGGL(k_dec_finalize, dim3(d.B), dim3(64), 0, s, d, tokens, out2);
 }

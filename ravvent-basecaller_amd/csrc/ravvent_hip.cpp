@@ -51,7 +51,7 @@ struct RvContext {
   int opt_att_nt = 0;
   int opt_side_ev = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
-  int lflash = 0, lkeys = 0;
+  int lflash = 0, lkeys = 0, lsplit = 1;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
@@ -373,6 +373,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   // k_dec_finalize exactly as the reference's whole-slab loop would (beam search only; greedy rows
   // keep sampling after their end token, so greedy decodes as one piece).
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
+  h->lsplit = nsplit;
   const int Wd = d.W;
   DecState part[4];
   DecParts parts{};
@@ -510,6 +511,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
 #define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(h, RV_EHIP, "%s: %s", #x, hipGetErrorString(e_)); return bail(RV_EHIP); } } while (0)
   HIPTRY(hipSetDevice(c.device));
   HIPTRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  configure_decode_kernels();
   const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
   const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
   const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
@@ -683,6 +685,8 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
     for (int i = 0; i < 16; ++i) dst[i] = (float)(ts[i] - ts[0]);
     return RV_OK;
   }
+  else if ((!strncmp(name, "step_", 5) || !strcmp(name, "parent_ids")) && h->lsplit > 1)
+    return fail(h, RV_ESTATE, "per-step records are laid out per sub-slab when decode_split > 1; read them with decode_split=1 or debug_taps=1");
   else if (!strcmp(name, "step_ids")) { src = d.step_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "parent_ids")) { src = d.parent_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "step_scores")) { src = d.step_scores; n = S * B * W; }
