@@ -111,6 +111,11 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       256 (two workgroups per CU) for slabs larger than the CU count),
  *          "flash_attend" (0/1, default 1: single-pass Luong attention over values only;
  *                       0 = two-pass keys-then-values dataflow of the reference),
+ *          "persistent_decode" (0/1, default 1: Luong beam search with beam <= 5, decoder_depth 1 and no
+ *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
+ *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.
+ *                       The step_ids / parent_ids / step_scores taps of a chunk then end at its own last
+ *                       step instead of the slab's),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around
  *                       the graph as a whole; 2: no graph, events around every kernel). */
 int rv_set_option(rv_handle h, const char* key, int32_t value);

@@ -91,6 +91,7 @@ struct DecState {
   float* call_probs;      // [B,L-1] exp(score_t - score_{t-1})
   int* call_len;          // [B] letters per chunk
   uint8_t lut[RV_MAX_VOCAB];   // token id -> upper-case letter, 0 for tokens the string form drops
+  int* chunk_steps;       // persistent decode: [B] steps each chunk ran (nullptr on the per-step graph path)
   int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
@@ -104,6 +105,11 @@ void launch_dec_cell(const DecState& d, int layer, const float* WcatT /*[512,256
                      const float* bias /*[512]*/, int step, hipStream_t s);
 // flash: single-pass Luong attend over `values` only (WmemT = W_mem^T [128,256]); else the two-pass kernel
 void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s);
+// Persistent decode (Luong beam search, W <= 5, one decoder cell, no taps): the whole loop in one launch,
+// the chunk's attention memory resident in registers; also writes S_dev[0..1].
+bool dec_persist_supported(const DecState& d);
+void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
+                        const float* bdec /*[512]*/, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
 struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; };
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s);   // S_dev[0] = max_g S_g, S_dev[1+g] = S_g

@@ -841,6 +841,405 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
   RV_STAMP(d, step, 8);
 }
 
+// =====================================================================================
+// Persistent decode: the WHOLE beam-search loop of one chunk in one workgroup, with the chunk's
+// attention memory resident ON CHIP.
+// The per-step attention is HBM-bound when `values` [T_m,256] fp32 (338 KB per chunk at T_m = 330)
+// is re-streamed every step (k_dec_attend_flash: 86.6 MB per step at B = 256).  A CU's register file
+// is 512 KB: thread (stream sid = tid>>4, sub = tid&15) loads rows t = sid + 32 it, columns
+// {4 sub + 64 m + 0..3} of its chunk ONCE into NIT*16 VGPRs and keeps them for all L-1 steps.
+// Chunks never interact inside the decode loop (the reference's loop only shares its stop test,
+// "until every row of the slab is finished"): each workgroup runs until ITS beams are finished and
+// records that step; k_dec_finalize extends earlier finishers exactly as the shared loop would
+// (end token, unchanged score -- SURVEY.md A.5).  No hipGraph, no per-step launches, no HBM stream:
+// per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
+// Luong attention, beam search, decoder_depth 1, W <= 5 (register budget: 176 resident + 16*? work).
+struct PersistLds {
+  int xT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, total;
+  __host__ __device__ PersistLds(int W) {
+    int o = 0;
+    xT = o; o += RV_E * WB;            // cell input [attention | h], k-major beam-minor
+    zb = o; o += W * RV_G;             // gate pre-activations
+    hS = o; o += W * RV_U;             // h of the beams (attention query)
+    cS = o; o += W * RV_U;
+    qp = o; o += W * RV_E;             // q' * log2(e)
+    part = o; o += 8 * W * RV_E;       // partial sums ([8][W][256] / [16][W][128])
+    hcT = o; o += (RV_U + RV_E) * WB;  // [h ; context] k-major beam-minor
+    att = o; o += W * RV_U;
+    ml = o; o += 32 * WB;              // per-stream max, then per-stream sum
+    mg = o; o += 2 * WB;               // merged max, 1/sum
+    lg = o; o += WB * RV_MAX_VOCAB;
+    fold = o; o += 8 * 16 * 16 * 4;    // wave-private fold slab: 4 streams x 4 float4 x 16 lanes
+    total = o;
+  }
+};
+
+template <int W, int NIT>
+__global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ WmemT, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
+                                                      const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/) {
+  constexpr int NT = 512;
+  extern __shared__ __align__(16) float dsm[];
+  const PersistLds L(W);
+  float* xT = dsm + L.xT;  float* zb = dsm + L.zb;  float* hS = dsm + L.hS;  float* cS = dsm + L.cS;
+  float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
+  float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
+  __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
+  __shared__ float s_lprob[WB];
+  __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
+
+  const int b = blockIdx.x, tid = threadIdx.x, Tm = d.Tm, V = d.V;
+  const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
+  const size_t row0 = (size_t)b * W;
+  const int steps = d.L - 1;
+
+  // ---- the chunk's attention memory -> registers (once)
+  float4 vr[NIT][4];
+  unsigned livebits = 0;
+  {
+    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * sub;
+    const uint8_t* mrow = d.mask + (size_t)b * Tm;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int t = sid + 32 * it, tc = min(t, Tm - 1);
+      const float* p = vbase + (size_t)tc * RV_E;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) vr[it][m] = *reinterpret_cast<const float4*>(p + 64 * m);
+      if (t < Tm && mrow[tc]) livebits |= 1u << it;       // _maybe_mask_score: padded steps never score
+    }
+  }
+  // ---- decoder initial state: zeros; start tokens; log_probs = [0, -inf, ...]
+  for (int i = tid; i < RV_E * WB; i += NT) xT[i] = 0.f;
+  for (int i = tid; i < W * RV_U; i += NT) cS[i] = 0.f;
+  for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
+  if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
+  if (tid < WB) {
+    s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
+    s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = 0;
+  }
+  if (tid == 0) s_allfin = 0;
+  const float bz = bdec[tid];
+  {
+    const float w0 = Wtok[(size_t)d.start_token * RV_G + tid] + bz;      // one-hot token row of the cell kernel + bias
+    for (int w = 0; w < W; ++w) zb[w * RV_G + tid] = w0;
+  }
+  __syncthreads();
+
+  int done_steps = steps;
+  const int tid0 = tid;
+  for (int step = 0; step < steps; ++step) {
+    // Thread coordinates are re-derived from an opaque copy each step: otherwise every LDS / global address
+    // of every phase is hoisted out of the loop and the hoisted values spill (the resident rows leave ~70 VGPRs).
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
+    RV_STAMP(d, step, 0);
+    // ================= cell: z = [attention | h] . Wcat + W_dec[token] + b
+    //   thread = (4 gate columns c4, K quarter kg): 64 float4 weight loads in batches of 8 (64 KB in flight per CU)
+    {
+      const int c4 = tid & 127, kg = tid >> 7;
+      f2 acc[W][2];
+#pragma unroll
+      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+      const float* wc = Wcat + (size_t)(64 * kg) * RV_G + 4 * c4;
+      const float* xk = xT + (64 * kg) * WB;
+#pragma unroll 1
+      for (int k0 = 0; k0 < 64; k0 += 8) {
+        float4 wr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float xv[WB];
+          *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB]);
+          if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB + 4]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+      }
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 1);
+    for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-quarter sums in fixed order, gate math, cell update
+      const int w = idx >> 7, u = idx & 127;
+      float z4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = g * RV_U + u;
+        z4[g] = (((part[(0 * W + w) * RV_G + col] + part[(1 * W + w) * RV_G + col]) + part[(2 * W + w) * RV_G + col]) +
+                 part[(3 * W + w) * RV_G + col]) + zb[w * RV_G + col];
+      }
+      const float c2 = fmaf(rv_sigmoid(z4[1]), cS[idx], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
+      const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
+      cS[idx] = c2; hS[idx] = hh; hcT[u * WB + w] = hh;
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 2);
+    // ================= q' = W_mem . h (times log2 e)
+    {
+      const int c4 = tid & 63, jg = tid >> 6;               // 8 j-groups of 16 rows of W_memT [128][256]
+      f2 acc[W][2];
+#pragma unroll
+      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll 1
+      for (int j0 = 0; j0 < 16; j0 += 8) {
+        float4 wm[8];
+        const float* wp = WmemT + (size_t)(16 * jg + j0) * RV_E + 4 * c4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float hv[WB];
+          *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + j0 + u) * WB]);
+          if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + j0 + u) * WB + 4]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].x, wm[u].y}, acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        *reinterpret_cast<float4*>(&part[(jg * W + w) * RV_E + 4 * c4]) =
+            make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+    }
+    __syncthreads();
+    for (int i = tid; i < W * RV_E; i += NT) {
+      const int w = i >> 8, col = i & 255;
+      float s0 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+      qp[i] = s0 * LOG2E;
+    }
+    __syncthreads();
+
+    RV_STAMP(d, step, 3);
+    // ================= scores from the resident rows: lane sub == w keeps beam w's NIT scores
+    float sc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) sc[it] = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      float4 qv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_E + 4 * sub + 64 * m]);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f2 pp = f2{0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          pp = __builtin_elementwise_fma(f2{vr[it][m].x, vr[it][m].y}, f2{qv[m].x, qv[m].y}, pp);
+          pp = __builtin_elementwise_fma(f2{vr[it][m].z, vr[it][m].w}, f2{qv[m].z, qv[m].w}, pp);
+        }
+        const float sw = row16_sum(pp.x + pp.y);
+        sc[it] = (sub == w && ((livebits >> it) & 1u)) ? sw : sc[it];
+      }
+    }
+    RV_STAMP(d, step, 4);
+    // ================= softmax over the chunk's T_m steps (exact two-pass: everything is on chip)
+    {
+      float m = -INFINITY;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) m = fmaxf(m, sc[it]);
+      if (sub < W) ml[sid * WB + sub] = m;
+      __syncthreads();
+      if (wv < W) {
+        const float ms = lane < 32 ? ml[lane * WB + wv] : -INFINITY;
+        const float Mg = wave_max_fast(ms);
+        if (lane == 0) mg[wv] = Mg;
+      }
+      __syncthreads();
+      const float Mg = sub < W ? mg[sub] : 0.f;
+      float lsum = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { sc[it] = exp2f(sc[it] - Mg); lsum += sc[it]; }   // all-masked chunk: NaN like the reference
+      if (sub < W) ml[sid * WB + sub] = lsum;
+      __syncthreads();
+      if (wv < W) {
+        const float ls = lane < 32 ? ml[lane * WB + wv] : 0.f;
+        const float tot = wave_sum_fast(ls);
+        if (lane == 0) mg[WB + wv] = 1.0f / tot;
+      }
+      __syncthreads();
+      const float inv = sub < W ? mg[WB + sub] : 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) sc[it] *= inv;           // alignments of beam `sub` on this stream's rows
+    }
+    RV_STAMP(d, step, 5);
+    // ================= context = sum_t alpha_t * values_t, one beam at a time (16-register accumulator)
+    {
+      float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (16 * 16 * 4));
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        f2 a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = f2{0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const float al = row_bcast(sc[it], w);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            a[2 * m] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][m].x, vr[it][m].y}, a[2 * m]);
+            a[2 * m + 1] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][m].z, vr[it][m].w}, a[2 * m + 1]);
+          }
+        }
+        // fold the wave's 4 streams (same columns) in ONE LDS round trip: every row parks its 4 column blocks,
+        // row r then sums block m = r over the 4 streams in fixed order.  DS operations of one wave execute in
+        // issue order, so the reads see the writes without a wait in between.
+#pragma unroll
+        for (int m = 0; m < 4; ++m) slab[(row * 4 + m) * 16 + sub] = make_float4(a[2 * m].x, a[2 * m].y, a[2 * m + 1].x, a[2 * m + 1].y);
+        asm volatile("" ::: "memory");
+        const float4 p0 = slab[(0 * 4 + row) * 16 + sub], p1 = slab[(1 * 4 + row) * 16 + sub];
+        const float4 p2 = slab[(2 * 4 + row) * 16 + sub], p3 = slab[(3 * 4 + row) * 16 + sub];
+        *reinterpret_cast<float4*>(&part[(wv * W + w) * RV_E + 4 * sub + 64 * row]) =
+            make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        asm volatile("" ::: "memory");
+      }
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 6);
+    for (int i = tid; i < W * RV_E; i += NT) {              // fixed-order reduction over the 8 waves
+      const int w = i >> 8, col = i & 255;
+      float s0 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
+      hcT[(RV_U + col) * WB + w] = s0;
+    }
+    __syncthreads();
+
+    RV_STAMP(d, step, 7);
+    // ================= attention = [h ; context] . W_att ; thread = (4 columns, 1 of 16 K-groups of 24)
+    {
+      const int d4 = tid & 31, kg = tid >> 5;
+      f2 acc[W][2];
+#pragma unroll
+      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll 1
+      for (int k0 = 0; k0 < 24; k0 += 8) {
+        float4 wa4[8];
+        const float* wa = d.W_att + (size_t)(24 * kg + k0) * RV_U + 4 * d4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wa4[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float hv[WB];
+          *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + k0 + u) * WB]);
+          if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + k0 + u) * WB + 4]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wa4[u].x, wa4[u].y}, acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wa4[u].z, wa4[u].w}, acc[w][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_U + 4 * d4]) =
+            make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+    }
+    __syncthreads();
+    for (int i = tid; i < W * RV_U; i += NT) {
+      const int w = i >> 7, col = i & 127;
+      float s0 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+      att[i] = s0;
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 8);
+    // ================= logits = attention . W_fc + b_fc
+    {
+      const int o = tid >> 4;
+      for (int ob = o; ob < W * V; ob += NT / 16) {
+        const int w = ob / V, v = ob % V;
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p = fmaf(att[w * RV_U + 8 * sub + i], s_wfc[(8 * sub + i) * V + v], p);
+        p = row16_sum(p) + s_wfc[RV_U * V + v];
+        if (sub == 0) lg[w * RV_MAX_VOCAB + v] = p;
+      }
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 9);
+    // ================= beam step (wave 0): log-softmax, finished masking, top-W, bookkeeping
+    if (tid < 64) {
+      const int w = lane / V, v = lane % V;
+      const bool cand = lane < W * V;
+      const size_t o = ((size_t)step * d.B + b) * W;
+      float val = -INFINITY;
+      if (cand) {
+        float m = lg[w * RV_MAX_VOCAB];
+        for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
+        float ssum = 0.f;
+        for (int x = 0; x < V; ++x) ssum += __expf(lg[w * RV_MAX_VOCAB + x] - m);
+        const float lse = __logf(ssum);
+        const bool fin = s_fin[w] != 0;
+        const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (lg[w * RV_MAX_VOCAB + v] - m) - lse;
+        val = s_lprob[w] + lp;
+      }
+      bool taken = !cand;
+      int my_word = 0, my_par = 0; float my_val = 0.f;
+      for (int k = 0; k < W; ++k) {
+        const float mx = wave_max_fast(taken ? -INFINITY : val);
+        const unsigned long long hit = __ballot(!taken && (val == mx || mx == -INFINITY));
+        const int win = __ffsll((long long)hit) - 1;
+        const float wval = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), win));
+        if (lane == win) taken = true;
+        if (lane == k) { my_word = win % V; my_par = win / V; my_val = wval; }
+      }
+      bool nf = false; int nl = 0;
+      if (lane < W) {
+        const bool pf = s_fin[my_par] != 0;
+        nf = pf || my_word == d.end_token;
+        nl = s_len[my_par] + (pf ? 0 : 1);
+      }
+      const unsigned long long fmask = __ballot(lane < W && nf);
+      if (lane < W) {      // all reads of the old bookkeeping happened above (same wave, program order)
+        d.step_ids[o + lane] = my_word; d.parent_ids[o + lane] = my_par; d.step_scores[o + lane] = my_val;
+        s_tok[lane] = my_word; s_fin[lane] = nf; s_lprob[lane] = my_val; s_len[lane] = nl; s_parent[lane] = my_par;
+      }
+      if (lane == 0) s_allfin = __popcll(fmask) == W;
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 10);
+    // ================= next-step state, gathered by parent beam (read all, barrier, write)
+    {
+      float na[(W * RV_U + NT - 1) / NT], nh[(W * RV_U + NT - 1) / NT], nc[(W * RV_U + NT - 1) / NT];
+      float wt[W];                                   // next step's one-hot token rows (consumed after the barrier)
+#pragma unroll
+      for (int w = 0; w < W; ++w) wt[w] = Wtok[(size_t)s_tok[w] * RV_G + tid];
+#pragma unroll
+      for (int r = 0; r < (W * RV_U + NT - 1) / NT; ++r) {
+        const int i = tid + NT * r;
+        if (i < W * RV_U) { const int w = i >> 7, e = i & 127, p = s_parent[w]; na[r] = att[p * RV_U + e]; nh[r] = hS[p * RV_U + e]; nc[r] = cS[p * RV_U + e]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < (W * RV_U + NT - 1) / NT; ++r) {
+        const int i = tid + NT * r;
+        if (i < W * RV_U) { const int w = i >> 7, e = i & 127; xT[e * WB + w] = na[r]; xT[(RV_U + e) * WB + w] = nh[r]; cS[i] = nc[r]; }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w) zb[w * RV_G + tid] = wt[w] + bz;
+    }
+    __syncthreads();
+    RV_STAMP(d, step, 11);
+    if (s_allfin) { done_steps = step + 1; break; }         // uniform: every thread reads the same LDS word
+  }
+  if (tid < W) { d.lengths[row0 + tid] = s_len[tid]; d.finished[row0 + tid] = (uint8_t)s_fin[tid]; }
+  if (tid == 0) d.chunk_steps[b] = done_steps;
+}
+
 // One 64-thread workgroup per chunk: the chunk's [S,W] ids/parents are staged in LDS so the
 // serial gather_tree back-trace runs on LDS latency, not on dependent global loads.
 __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens, float* out2) {
@@ -851,7 +1250,7 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
   // S: steps the reference loop runs for the WHOLE slab (until every row is finished); So: steps this
   // sub-slab actually ran.  For s in [So, S) all of its beams are finished: the reference emits the
   // end token at an unchanged top-1 score there, which is what is written below.
-  const int S = d.S_dev[0], So = d.S_dev[1 + d.part];
+  const int S = d.S_dev[0], So = d.chunk_steps ? d.chunk_steps[b] : d.S_dev[1 + d.part];
   (void)s_S;
   int32_t* tk = tokens + (size_t)b * steps;
   if (d.greedy) {
@@ -923,7 +1322,39 @@ __global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
   if (lane == 0) p.S_dev[0] = S;
 }
 
+// persistent decode: S of the slab = the slowest chunk's step count
+__global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict__ chunk_steps, int B, int* __restrict__ S_dev) {
+  __shared__ int sm[4];
+  int m = 0;
+  for (int i = threadIdx.x; i < B; i += 256) m = max(m, chunk_steps[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int S = max(max(sm[0], sm[1]), max(sm[2], sm[3])); S_dev[0] = S; S_dev[1] = S; }
+}
+
 }  // namespace
+
+template <int W>
+static void launch_persist_w(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec, hipStream_t s) {
+  const size_t shm = sizeof(float) * PersistLds(W).total;
+  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
+  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
+  else hipLaunchKernelGGL((k_dec_persist<W, 11>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
+}
+bool dec_persist_supported(const DecState& d) {
+  return !d.greedy && d.attention == 0 && d.depth == 1 && d.W <= 5 && d.Tm <= 352 && !d.step_logits && !d.step_align;
+}
+void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec, hipStream_t s) {
+  switch (d.W) {
+    case 1: launch_persist_w<1>(d, WmemT, Wcat, Wtok, bdec, s); break;
+    case 2: launch_persist_w<2>(d, WmemT, Wcat, Wtok, bdec, s); break;
+    case 3: launch_persist_w<3>(d, WmemT, Wcat, Wtok, bdec, s); break;
+    case 4: launch_persist_w<4>(d, WmemT, Wcat, Wtok, bdec, s); break;
+    default: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, s); break;
+  }
+  hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
+}
 
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s) {
   hipLaunchKernelGGL(k_dec_reduce_steps, dim3(1), dim3(64), 0, s, p);
@@ -991,6 +1422,11 @@ static void configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_attend<W, 11, 44>), sizeof(float) * AttLds(W, 352, false).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), sizeof(float) * AttLds(W, 0, true, 256).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), sizeof(float) * AttLds(W, 0, true, 512).total);
+  if constexpr (W <= 5) {
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2>), sizeof(float) * PersistLds(W).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8>), sizeof(float) * PersistLds(W).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11>), sizeof(float) * PersistLds(W).total);
+  }
 }
 void configure_decode_kernels() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -50,6 +50,9 @@ struct RvContext {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int opt_att_nt = 0;
   int opt_side_ev = 0;
+  int opt_persist = 1;                      // whole beam-search loop in one launch, attention memory register-resident
+  int* d_chunk_steps = nullptr;
+  int lpersist = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0, lsplit = 1;
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
@@ -373,6 +376,9 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   // k_dec_finalize exactly as the reference's whole-slab loop would (beam search only; greedy rows
   // keep sampling after their end token, so greedy decodes as one piece).
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
+  d.chunk_steps = nullptr;
+  h->lpersist = (h->opt_persist && h->lflash && !h->opt_taps && dec_persist_supported(d)) ? 1 : 0;
+  if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
   h->lsplit = nsplit;
   const int Wd = d.W;
   DecState part[4];
@@ -407,7 +413,11 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
     return RV_OK;
   };
-  if (h->opt_graph && h->opt_profile != 2) {
+  if (h->lpersist) {
+    part[0] = d; part[0].part = 0; parts.n = 1;
+    Scope sc(h, "dec_persist");
+    launch_dec_persist(d, h->d_WmemT, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b, s);
+  } else if (h->opt_graph && h->opt_profile != 2) {
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
@@ -439,7 +449,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   float* o2 = (dev_out && out2) ? out2 : h->out2;
   {
     Scope sc(h, "dec_finalize");
-    launch_dec_reduce_steps(parts, s);
+    if (!h->lpersist) launch_dec_reduce_steps(parts, s);
     for (int g = 0; g < parts.n; ++g) {
       const size_t b0 = parts.n == 1 ? 0 : (size_t)B * g / parts.n;
       launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s);
@@ -556,6 +566,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &d.step_logits, L * N * V));
   TRY(dalloc(h, &d.nfin, 4 * (L + 1)));
   TRY(dalloc(h, &d.S_dev, 8));
+  TRY(dalloc(h, &h->d_chunk_steps, (size_t)c.max_batch));
   for (int g = 0; g < 3; ++g) {
     HIPTRY(hipStreamCreateWithFlags(&h->side[g], hipStreamNonBlocking));
     HIPTRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
@@ -654,6 +665,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
+  else if (!strcmp(key, "persistent_decode")) h->opt_persist = value != 0;
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");

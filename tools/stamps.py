@@ -12,5 +12,9 @@ x = (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
 for _ in range(3):
     bc.beam_search_prediction(x, 5, 48)
     ts = bc.get_tensor("dbg_stamps")
+    if os.environ.get("RV_PERSIST", "1") != "0":
+        pn = ["cell", "gates", "qprime", "scores", "softmax", "context", "ctx-reduce", "att-layer", "logits", "beam", "gather"]
+        print(" ".join(f"{n}={ts[i+1]-ts[i]:.0f}" for i, n in enumerate(pn)), "step total", ts[11] - ts[0])
+        continue
     names = ["entry", "prologue", "qprime", "sweep", "merge", "E att", "F logits", "G beam", "H/end"]
     print(" ".join(f"{n}={ts[i]-ts[i-1] if i else 0:.0f}" for i, n in enumerate(names[:8])), "total", ts[7])
