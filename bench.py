@@ -41,6 +41,7 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
         "decode_graph": B * W * S * (369408 + 768 * Tm),
+        "dec_persist": B * W * S * (369408 + 768 * Tm),      # the whole decode loop is one launch
         "dec_cell": B * W * 2 * 256 * 512,
     }.get(kernel)
 
@@ -87,6 +88,8 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-decode", action="store_true",
+                    help="A/B: per-step decode kernels in a hipGraph instead of the one-launch persistent decode")
     ap.add_argument("--attend-threads", type=int, default=0, help="0 auto | 256 | 512 (library option attend_threads)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real path) | gloo (control-flow rehearsal: ranks may share a GPU, the gather goes through host memory)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-kernel event pass over the decode loop")
@@ -121,6 +124,8 @@ def main():
     flat = bc.init_random_weights(seed=22)            # Keras-default initialisers, seed as ravvent.py:9
     if args.attend_threads:
         bc.set_option("attend_threads", args.attend_threads)
+    if args.per_step_decode:
+        bc.set_option("persistent_decode", 0)
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=rank)
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
     packed = gathered = None

@@ -859,14 +859,14 @@ struct PersistLds {
   __host__ __device__ PersistLds(int W) {
     int o = 0;
     xT = o; o += RV_E * WB;            // cell input [attention | h], k-major beam-minor
-    zb = o; o += W * RV_G;             // gate pre-activations
+    zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     hS = o; o += W * RV_U;             // h of the beams (attention query)
     cS = o; o += W * RV_U;
     qp = o; o += W * RV_E;             // q' * log2(e)
     part = o; o += 8 * W * RV_E;       // partial sums ([8][W][256] / [16][W][128])
     hcT = o; o += (RV_U + RV_E) * WB;  // [h ; context] k-major beam-minor
     att = o; o += W * RV_U;
-    ml = o; o += 32 * WB;              // per-stream max, then per-stream sum
+    ml = o; o += 64 * WB;              // per-stream max [32][WB], per-stream sum [32][WB]
     mg = o; o += 2 * WB;               // merged max, 1/sum
     lg = o; o += WB * RV_MAX_VOCAB;
     fold = o; o += 8 * 16 * 16 * 4;    // wave-private fold slab: 4 streams x 4 float4 x 16 lanes
@@ -917,11 +917,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = 0;
   }
   if (tid == 0) s_allfin = 0;
-  const float bz = bdec[tid];
-  {
-    const float w0 = Wtok[(size_t)d.start_token * RV_G + tid] + bz;      // one-hot token row of the cell kernel + bias
-    for (int w = 0; w < W; ++w) zb[w * RV_G + tid] = w0;
-  }
+  for (int i = tid; i < V * RV_G; i += NT) zb[i] = Wtok[i] + bdec[i & (RV_G - 1)];   // W_dec[one_hot(v)] + b, resident
   __syncthreads();
 
   int done_steps = steps;
@@ -974,7 +970,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       for (int g = 0; g < 4; ++g) {
         const int col = g * RV_U + u;
         z4[g] = (((part[(0 * W + w) * RV_G + col] + part[(1 * W + w) * RV_G + col]) + part[(2 * W + w) * RV_G + col]) +
-                 part[(3 * W + w) * RV_G + col]) + zb[w * RV_G + col];
+                 part[(3 * W + w) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
       }
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[idx], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
@@ -1045,34 +1041,28 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
     }
     RV_STAMP(d, step, 4);
-    // ================= softmax over the chunk's T_m steps (exact two-pass: everything is on chip)
+    // ================= softmax over the chunk's T_m steps: per-stream (max, sum), one fixed-order merge per beam
     {
       float m = -INFINITY;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) m = fmaxf(m, sc[it]);
-      if (sub < W) ml[sid * WB + sub] = m;
+      float lsum = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { sc[it] = exp2f(sc[it] - m); lsum += sc[it]; }   // stream without live rows: NaN, dropped below
+      if (sub < W) { ml[sid * WB + sub] = m; ml[(32 + sid) * WB + sub] = m == -INFINITY ? 0.f : lsum; }
       __syncthreads();
       if (wv < W) {
         const float ms = lane < 32 ? ml[lane * WB + wv] : -INFINITY;
+        const float ls = lane < 32 ? ml[(32 + lane) * WB + wv] : 0.f;
         const float Mg = wave_max_fast(ms);
-        if (lane == 0) mg[wv] = Mg;
+        const float tot = wave_sum_fast(ms == -INFINITY ? 0.f : ls * exp2f(ms - Mg));   // all-masked chunk: 0 -> NaN like the reference
+        if (lane == 0) { mg[wv] = Mg; mg[WB + wv] = Mg == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tot; }
       }
       __syncthreads();
-      const float Mg = sub < W ? mg[sub] : 0.f;
-      float lsum = 0.f;
+      const float f = (sub < W && m != -INFINITY) ? exp2f(m - mg[sub]) * mg[WB + sub] : 0.f;
+      const float nanv = (sub < W && mg[WB + sub] != mg[WB + sub]) ? mg[WB + sub] : 0.f;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) { sc[it] = exp2f(sc[it] - Mg); lsum += sc[it]; }   // all-masked chunk: NaN like the reference
-      if (sub < W) ml[sid * WB + sub] = lsum;
-      __syncthreads();
-      if (wv < W) {
-        const float ls = lane < 32 ? ml[lane * WB + wv] : 0.f;
-        const float tot = wave_sum_fast(ls);
-        if (lane == 0) mg[WB + wv] = 1.0f / tot;
-      }
-      __syncthreads();
-      const float inv = sub < W ? mg[WB + sub] : 0.f;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) sc[it] *= inv;           // alignments of beam `sub` on this stream's rows
+      for (int it = 0; it < NIT; ++it) sc[it] = m == -INFINITY ? nanv : sc[it] * f;   // alignments of beam `sub` on this stream's rows
     }
     RV_STAMP(d, step, 5);
     // ================= context = sum_t alpha_t * values_t, one beam at a time (16-register accumulator)
@@ -1215,9 +1205,6 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     // ================= next-step state, gathered by parent beam (read all, barrier, write)
     {
       float na[(W * RV_U + NT - 1) / NT], nh[(W * RV_U + NT - 1) / NT], nc[(W * RV_U + NT - 1) / NT];
-      float wt[W];                                   // next step's one-hot token rows (consumed after the barrier)
-#pragma unroll
-      for (int w = 0; w < W; ++w) wt[w] = Wtok[(size_t)s_tok[w] * RV_G + tid];
 #pragma unroll
       for (int r = 0; r < (W * RV_U + NT - 1) / NT; ++r) {
         const int i = tid + NT * r;
@@ -1229,8 +1216,6 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         const int i = tid + NT * r;
         if (i < W * RV_U) { const int w = i >> 7, e = i & 127; xT[e * WB + w] = na[r]; xT[(RV_U + e) * WB + w] = nh[r]; cS[i] = nc[r]; }
       }
-#pragma unroll
-      for (int w = 0; w < W; ++w) zb[w * RV_G + tid] = wt[w] + bz;
     }
     __syncthreads();
     RV_STAMP(d, step, 11);

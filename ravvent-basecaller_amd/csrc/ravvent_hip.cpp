@@ -365,10 +365,6 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     d.step_align = nullptr;
     if (!greedy) d.step_logits = nullptr;
   }
-  for (int k = 0; k < d.depth; ++k) {     // get_initial_state: all zeros (basecaller.py:305)
-    HIPCHK(h, hipMemsetAsync(d.xh + k * d.ls_xh, 0, sizeof(float) * N * RV_E, s));
-    HIPCHK(h, hipMemsetAsync(d.c + k * d.ls_c, 0, sizeof(float) * N * RV_U, s));
-  }
 
   // The slab decodes as `nsplit` independent sub-slabs on concurrent streams (inside one hipGraph):
   // while one sub-slab is in its HBM-bound attention sweep another runs its latency-bound cell /
@@ -380,6 +376,12 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   h->lpersist = (h->opt_persist && h->lflash && !h->opt_taps && dec_persist_supported(d)) ? 1 : 0;
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
   h->lsplit = nsplit;
+  if (!h->lpersist) {
+    for (int k = 0; k < d.depth; ++k) {     // get_initial_state: all zeros (basecaller.py:305); the persistent kernel keeps state in LDS
+      HIPCHK(h, hipMemsetAsync(d.xh + k * d.ls_xh, 0, sizeof(float) * N * RV_E, s));
+      HIPCHK(h, hipMemsetAsync(d.c + k * d.ls_c, 0, sizeof(float) * N * RV_U, s));
+    }
+  }
   const int Wd = d.W;
   DecState part[4];
   DecParts parts{};
@@ -399,7 +401,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     if (p.step_align) p.step_align += (size_t)steps * Wd * Tm * b0;
     p.nfin = d.nfin + g * (c.max_output_len + 1);
     parts.nfin[g] = p.nfin; parts.B[g] = p.B;
-    launch_dec_init(p, s);
+    if (!h->lpersist) launch_dec_init(p, s);
   }
   auto enqueue = [&](bool profiled) -> int {
     for (int g = 1; g < nsplit; ++g) {

@@ -8,7 +8,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 python3 - <<'PY'
 import csv, glob, collections, json, os
 root = os.environ["GRAFT_REPO_ROOT"]
-names = {"k_dec_attend_flash": "dec_attend", "k_dec_attend<": "dec_attend_two_pass", "k_dec_cell": "dec_cell",
+names = {"k_dec_persist": "dec_persist", "k_dec_attend_flash": "dec_attend", "k_dec_attend<": "dec_attend_two_pass", "k_dec_cell": "dec_cell",
          "k_gemm_f32<2, 2": "gemm_inproj", "k_lstm_rec<2, 0": "lstm_rec_l1p", "k_lstm_rec<2, 1": "lstm_rec_raw_l0",
          "k_lstm_rec<2, 5": "lstm_rec_event_l0"}
 out = collections.defaultdict(lambda: {"fetch_kb": [], "write_kb": []})
