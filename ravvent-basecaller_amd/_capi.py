@@ -35,6 +35,15 @@ SYMBOLS = [
     ("rv_reset_profile", c_int32, [c_void_p]),
     ("rv_detect_events", c_int32, [c_void_p, c_size_t, c_int32, c_int32, c_double, c_double, c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
+    # include/ravvent_merge.h
+    ("rv_merge_calls", c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                 c_int64, POINTER(c_int64)]),
+    ("rv_merger_create", c_int32, [c_int32, c_int32, POINTER(c_void_p)]),
+    ("rv_merger_append", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+    ("rv_merger_result", c_int32, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int64)]),
+    ("rv_merger_destroy", None, [c_void_p]),
+    ("rv_local_align", c_int32, [c_char_p, c_int32, c_char_p, c_int32, c_int32, c_char_p, c_char_p, c_int32, _I,
+                                 POINTER(c_double), _I, _I]),
 ]
 
 _lib = None

@@ -220,7 +220,7 @@ class Basecaller:
                           torch.empty(shape2, dtype=torch.float32, device=self.device))
         return cache[key]
 
-    def beam_search_calls(self, input_data, beam_width, max_output_len):
+    def beam_search_calls(self, input_data, beam_width, max_output_len, arrays: bool = False):
         """beam_search_prediction + the evaluators' post-processing fused on the device
         (ravvent_performance_evaluator.py:55,66-70): returns (seqs: list[str], probs: list[np.ndarray])
         where probs[i] = calc_prob_logits_beam_search_scores(scores)[i][:len(seqs[i])]."""
@@ -229,7 +229,7 @@ class Basecaller:
             return self.beam_search_calls(tuple(None if k is None else k.cpu().numpy() for k in keep)
                                           if self.input_data_type == "joint" else
                                           (keep[0] if keep[0] is not None else keep[1]).cpu().numpy(),
-                                          beam_width, max_output_len)
+                                          beam_width, max_output_len, arrays)
         L = _as_int(max_output_len)
         steps = max(L - 1, 0)
         lut = np.zeros(8, np.uint8)
@@ -242,9 +242,16 @@ class Basecaller:
         self._check(self._lib.rv_beam_search_calls(self._h, pr, pe, B, Tr, Te, int(beam_width), L, p(lut), p(bases),
                                                    p(lens), p(probs), ctypes.byref(S)), "rv_beam_search_calls")
         self.last_steps = S.value
+        if arrays:
+            return bases, probs, lens
         flat = bases.tobytes()
         seqs = [flat[i * steps:i * steps + int(n)].decode("ascii") for i, n in enumerate(lens)]
         return seqs, [probs[i, :int(n)] for i, n in enumerate(lens)]
+
+    def beam_search_call_arrays(self, input_data, beam_width, max_output_len):
+        """beam_search_calls without per-chunk Python objects: (bases u8 [B, L-1], probs f32 [B, L-1], lengths i32 [B]),
+        the layout `merger.Merger.merge_arrays` / `StreamingMerger.append` (rv_merge_calls) take."""
+        return self.beam_search_calls(input_data, beam_width, max_output_len, arrays=True)
 
     def tokens_to_nuc_sequences(self, result_tokens):
         """basecaller.py:289-294"""

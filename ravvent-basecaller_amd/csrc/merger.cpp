@@ -1,0 +1,430 @@
+// Read-level stitching of per-chunk calls: the host step the reference times as t_merge
+// (/root/reference/ravvent_performance_evaluator.py:73-75 -> /root/reference/merger.py:155-248).
+//
+// Per chunk pair: local alignment of the last 25 merged bases with the first 25 appended bases
+// (merger.py:163-172, Biopython pairwise2.align.localms / localds, first alignment of the list), a
+// per-column pick by the higher per-base probability (SingleMergerByLogits, merger.py:88-119), splice
+// (merger.py:236-245).  The reference rebuilds its Python string per chunk (quadratic in read length);
+// here the merged read is one growing buffer and a pair costs a 25x25 DP.
+//
+// Bio.pairwise2 is a third-party dependency absent from the reference tree; its affine local
+// alignment, including the order in which co-optimal tracebacks are produced (algns[0]), is restated
+// from the published algorithm of Biopython 1.72-1.81.  Arithmetic is double like CPython's; the
+// equality tests use the same rint(x*1000+0.5) buckets and the same exact comparisons.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/ravvent_merge.h"
+
+namespace {
+
+constexpr int kMaxAlignments = 1000;     // pairwise2.MAX_ALIGNMENTS
+
+struct ScoreSet {
+  bool matrix;
+  double match, mismatch, open, extend;
+  double m[4][4];
+};
+
+bool score_set(int id, ScoreSet* s) {    // merger.py:124-147
+  static const double m2[4][4] = {{10, -3, -1, -4}, {-3, 9, -5, 0}, {-1, -5, 7, -3}, {-4, 0, -3, 8}};
+  memset(s, 0, sizeof *s);
+  switch (id) {
+    case 0: *s = ScoreSet{false, 1.0, -1.0, -1.0, -0.2, {}}; return true;
+    case 1: *s = ScoreSet{false, 5.0, -4.0, -3.0, -0.1, {}}; return true;
+    case 2:
+      s->matrix = true; s->open = -9.0; s->extend = -2.0;
+      memcpy(s->m, m2, sizeof m2);
+      return true;
+    default: return false;
+  }
+}
+
+inline int base_index(char c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+inline long long rint1000(double x) { return (long long)(x * 1000 + 0.5); }   // pairwise2.rint: int() truncates toward zero
+
+inline double affine(int length, double open, double extend) {   // calc_affine_penalty, penalize_extend_when_opening=False
+  if (length <= 0) return 0.0;
+  double p = open + extend * length;
+  p -= extend;
+  return p;
+}
+
+struct Start { double score; int row, col; };
+struct Item { std::string a, b; int end; bool has_end; int row, col; bool col_gap; int trace; };
+struct Aligned { std::string a, b; double score; int begin, end; };
+
+struct Aligner {
+  std::string A, B;
+  int lenA = 0, lenB = 0;
+  ScoreSet sc;
+  std::vector<double> score;     // (lenA+1) x (lenB+1)
+  std::vector<int> trace;        // -1 = None (border)
+  std::vector<double> col_score;
+  std::vector<int> bidx;
+  std::vector<Start> starts;
+  double best = 0;
+  int W = 0;
+
+  double& S(int r, int c) { return score[(size_t)r * W + c]; }
+  int& T(int r, int c) { return trace[(size_t)r * W + c]; }
+
+  double match_fn(char a, char b) const {
+    if (!sc.matrix) return a == b ? sc.match : sc.mismatch;
+    return sc.m[base_index(a)][base_index(b)];
+  }
+
+  void fill() {                  // _make_score_matrix_fast: local, penalize_end_gaps (False, False)
+    W = lenB + 1;
+    score.resize((size_t)(lenA + 1) * W);
+    trace.resize((size_t)(lenA + 1) * W);
+    col_score.resize(lenB + 1);
+    bidx.resize(lenB + 1);
+    const double open = sc.open, extend = sc.extend;
+    const double first_gap = affine(1, open, extend);
+    double local_max = 0;
+    for (int c = 0; c <= lenB; ++c) { score[c] = 0.0; trace[c] = -1; }
+    col_score[0] = 0.0;
+    for (int i = 1; i <= lenB; ++i) col_score[i] = affine(i, 2 * open, extend);
+    // Cells of one row form a dependent chain (row_score and the left neighbour), ~25 cycles each; four rows are
+    // swept as a skewed wavefront so that four independent chains are in flight.  Every cell still sees exactly
+    // the operands the row-major loop of the reference gives it.
+    for (int c = 1; c <= lenB; ++c) bidx[c] = sc.matrix ? base_index(B[c - 1]) : 0;
+    for (int r0 = 1; r0 <= lenA; r0 += 4) {
+      const int nr = std::min(4, lenA - r0 + 1);
+      double row_score[4];
+      for (int k = 0; k < nr; ++k) {
+        row_score[k] = affine(r0 + k, 2 * open, extend);
+        score[(size_t)(r0 + k) * W] = 0.0; trace[(size_t)(r0 + k) * W] = -1;
+      }
+      for (int d = 0; d < lenB + nr - 1; ++d) {
+        for (int k = 0; k < nr; ++k) {
+          const int col = d - k + 1;
+          if (col < 1 || col > lenB) continue;
+          const int row = r0 + k;
+          const double* up = &score[(size_t)(row - 1) * W];
+          double* cur = &score[(size_t)row * W];
+          const char a = A[row - 1];
+          const double mm = sc.matrix ? sc.m[base_index(a)][bidx[col]] : (a == B[col - 1] ? sc.match : sc.mismatch);
+          const double nogap = up[col - 1] + mm;
+          double row_open, row_extend, col_open, col_extend;
+          if (row == lenA) { row_open = cur[col - 1]; row_extend = row_score[k]; }
+          else { row_open = cur[col - 1] + first_gap; row_extend = row_score[k] + extend; }
+          const double rs = row_open > row_extend ? row_open : row_extend;
+          row_score[k] = rs;
+          if (col == lenB) { col_open = up[col]; col_extend = col_score[col]; }
+          else { col_open = up[col] + first_gap; col_extend = col_score[col] + extend; }
+          const double cs = col_open > col_extend ? col_open : col_extend;
+          col_score[col] = cs;
+          double b = cs > rs ? cs : rs;
+          b = nogap > b ? nogap : b;
+          local_max = local_max > b ? local_max : b;
+          cur[col] = b < 0 ? 0.0 : b;
+          // rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y)): five conversions per cell instead of eight
+          const long long ro = rint1000(row_open), re = rint1000(row_extend), co = rint1000(col_open), ce = rint1000(col_extend);
+          const long long ng = rint1000(nogap);
+          const long long rr = ro > re ? ro : re, cr = co > ce ? co : ce;
+          long long br = rr > cr ? rr : cr; br = ng > br ? ng : br;
+          int t = ng == br ? 2 : 0;
+          if (rr == br) t += (ro == rr ? 1 : 0) + (re == rr ? 8 : 0);
+          if (cr == br) t += (co == cr ? 4 : 0) + (ce == cr ? 16 : 0);
+          trace[(size_t)row * W + col] = t;
+        }
+      }
+    }
+    best = local_max;
+  }
+
+  void find_start(std::vector<Start>& st) {
+    st.clear();
+    const size_t n = (size_t)(lenA + 1) * W;
+    for (size_t i = 0; i < n; ++i) {
+      const double s = score[i];
+      const double d = s > best ? s - best : best - s;
+      if (d * 1000 + 0.5 < 1.0) st.push_back({s, (int)(i / W), (int)(i % W)});   // rint(abs(s - best)) <= rint(0)
+    }
+  }
+
+  static void rev_append(std::string& dst, const std::string& src, int from /*inclusive*/, int to /*exclusive, going down*/) {
+    for (int i = from; i > to; --i) dst.push_back(src[i]);
+  }
+
+  void finish_backtrace(std::string& a, std::string& b, int row, int col) {
+    if (row) rev_append(a, A, row - 1, -1);
+    if (col) rev_append(b, B, col - 1, -1);
+    if (row > col) b.append(a.size() - b.size(), '-');
+    else if (col > row) a.append(b.size() - a.size(), '-');
+  }
+
+  // direction_col: walk left (gap in A) else up (gap in B); target = how far the border is
+  bool find_gap_open(Item& it, std::vector<Item>& in_process, bool direction_col, int target) {
+    bool dead_end = false;
+    const double target_score = S(it.row, it.col);
+    for (int n = 0; n < target; ++n) {
+      if (direction_col) { it.col -= 1; it.a.push_back('-'); it.b.push_back(B[it.col]); }
+      else { it.row -= 1; it.a.push_back(A[it.row]); it.b.push_back('-'); }
+      const double actual = S(it.row, it.col) + affine(n + 1, sc.open, sc.extend);
+      if (S(it.row, it.col) == best) { dead_end = true; break; }
+      const int t = T(it.row, it.col);
+      if (rint1000(actual) == rint1000(target_score) && n > 0) {
+        if (t <= 0) break;
+        Item br = it; br.trace = t;
+        in_process.push_back(br);
+      }
+      if (t <= 0) dead_end = true;
+    }
+    return dead_end;
+  }
+
+  // first alignment of _clean_alignments(_recover_alignments(...)); reverse = second attempt on transposed matrices
+  bool recover(const std::vector<Start>& starts, bool reverse, Aligned* out) {
+    std::vector<Item> in_process;
+    int begin = 0;
+    double sc_last = 0;
+    for (const Start& st : starts) {
+      const double s = st.score; const int row = st.row, col = st.col;
+      sc_last = s;
+      begin = 0;
+      bool zero_ext = false;
+      for (const Start& o : starts) if (o.row == row - 1 && o.col == col - 1 && o.score == s) { zero_ext = true; break; }
+      if (zero_ext) continue;
+      if (s <= 0) continue;
+      const int t = T(row, col);
+      if (t < 0) continue;
+      if ((t - t % 2) % 4 == 2) T(row, col) = 2; else continue;
+      Item it;
+      it.end = -std::max(lenA - row, lenB - col);
+      it.has_end = it.end != 0;
+      const int cd = lenB - col, rd = lenA - row;
+      if (cd > rd) it.a.append(cd - rd, '-');
+      rev_append(it.a, A, lenA - 1, row - 1);
+      if (rd > cd) it.b.append(rd - cd, '-');
+      rev_append(it.b, B, lenB - 1, col - 1);
+      it.row = row; it.col = col; it.col_gap = false; it.trace = T(row, col);
+      in_process.push_back(std::move(it));
+    }
+    int n_tracebacks = 0;
+    while (!in_process.empty() && n_tracebacks < kMaxAlignments) {
+      bool dead_end = false;
+      Item it = std::move(in_process.back());
+      in_process.pop_back();
+      int trace = it.trace;
+      while ((it.row > 0 || it.col > 0) && !dead_end) {
+        // state before this move (pushed again when the cell has another way out); the aligned strings only
+        // ever grow, so the earlier state is a prefix of the current one
+        const size_t c_na = it.a.size(), c_nb = it.b.size();
+        const int c_row = it.row, c_col = it.col; const bool c_gap = it.col_gap;
+        if (trace <= 0) {
+          if (it.col && it.col_gap) dead_end = true;
+          else finish_backtrace(it.a, it.b, it.row, it.col);
+          break;
+        } else if (trace % 2 == 1) {
+          trace -= 1;
+          if (it.col_gap) dead_end = true;
+          else { it.col -= 1; it.a.push_back('-'); it.b.push_back(B[it.col]); it.col_gap = false; }
+        } else if (trace % 4 == 2) {
+          trace -= 2;
+          it.row -= 1; it.col -= 1;
+          it.a.push_back(A[it.row]); it.b.push_back(B[it.col]);
+          it.col_gap = false;
+        } else if (trace % 8 == 4) {
+          trace -= 4;
+          it.row -= 1;
+          it.a.push_back(A[it.row]); it.b.push_back('-');
+          it.col_gap = true;
+        } else if (trace == 8 || trace == 24) {
+          trace -= 8;
+          if (it.col_gap) dead_end = true;
+          else { it.col_gap = false; dead_end = find_gap_open(it, in_process, true, it.col); }
+        } else if (trace == 16) {
+          trace -= 16;
+          it.col_gap = true;
+          dead_end = find_gap_open(it, in_process, false, it.row);
+        }
+        if (trace) {
+          Item cache;
+          cache.a.assign(it.a, 0, c_na); cache.b.assign(it.b, 0, c_nb);
+          cache.end = it.end; cache.has_end = it.has_end; cache.row = c_row; cache.col = c_col; cache.col_gap = c_gap;
+          cache.trace = trace;
+          in_process.push_back(std::move(cache));
+        }
+        trace = T(it.row, it.col);
+        if (S(it.row, it.col) == best) dead_end = true;
+        else if (S(it.row, it.col) <= 0) { begin = std::max(it.row, it.col); trace = 0; }
+      }
+      if (!dead_end) {
+        ++n_tracebacks;
+        std::string ra(it.a.rbegin(), it.a.rend()), rb(it.b.rbegin(), it.b.rend());
+        int end = it.has_end ? it.end + (int)ra.size() : (int)ra.size();     // _clean_alignments
+        if (begin < end) {
+          out->a = reverse ? rb : ra;
+          out->b = reverse ? ra : rb;
+          out->score = sc_last; out->begin = begin; out->end = end;
+          return true;
+        }
+      }
+    }
+    return false;
+  }
+
+  void transpose() {             // _reverse_matrices + swapped sequences
+    static const int rt[32] = {0, 4, 2, 6, 1, 5, 3, 7, 16, 20, 18, 22, 17, 21, 19, 23,
+                               8, 12, 10, 14, 9, 13, 11, 15, 24, 28, 26, 30, 25, 29, 27, 31};
+    std::vector<double> s2((size_t)(lenB + 1) * (lenA + 1));
+    std::vector<int> t2(s2.size());
+    for (int c = 0; c <= lenB; ++c)
+      for (int r = 0; r <= lenA; ++r) {
+        s2[(size_t)c * (lenA + 1) + r] = S(r, c);
+        const int t = T(r, c);
+        t2[(size_t)c * (lenA + 1) + r] = t < 0 ? -1 : rt[t];
+      }
+    score.swap(s2); trace.swap(t2);
+    std::swap(A, B); std::swap(lenA, lenB);
+    W = lenB + 1;
+  }
+
+  // pairwise2.align.local{ms,ds}(a, b, ...)[0]; false = empty list
+  bool align(const char* a, int la, const char* b, int lb, Aligned* out) {
+    if (la <= 0 || lb <= 0) return false;
+    A.assign(a, la); B.assign(b, lb); lenA = la; lenB = lb;
+    fill();
+    find_start(starts);
+    if (recover(starts, false, out)) return true;
+    transpose();
+    for (Start& s : starts) std::swap(s.row, s.col);
+    return recover(starts, true, out);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rv_local_align(const char* a, int32_t len_a, const char* b, int32_t len_b, int32_t scores_id, char* out_a, char* out_b,
+                   int32_t cap, int32_t* out_len, double* score, int32_t* begin, int32_t* end) {
+  Aligner al;
+  if (!score_set(scores_id, &al.sc)) return RV_MERGE_EINVAL;
+  if (len_a < 0 || len_b < 0 || (!a && len_a) || (!b && len_b) || !out_len) return RV_MERGE_EINVAL;
+  if (al.sc.matrix) {
+    for (int i = 0; i < len_a; ++i) if (base_index(a[i]) < 0) return RV_MERGE_EALPHABET;
+    for (int i = 0; i < len_b; ++i) if (base_index(b[i]) < 0) return RV_MERGE_EALPHABET;
+  }
+  Aligned r;
+  if (!al.align(a, len_a, b, len_b, &r)) { *out_len = 0; return 0; }
+  if ((int)r.a.size() > cap || !out_a || !out_b) return RV_MERGE_ESPACE;
+  memcpy(out_a, r.a.data(), r.a.size());
+  memcpy(out_b, r.b.data(), r.b.size());
+  *out_len = (int32_t)r.a.size();
+  if (score) *score = r.score;
+  if (begin) *begin = r.begin;
+  if (end) *end = r.end;
+  return 1;
+}
+
+}  // extern "C"
+
+// Merger.merge as a resumable loop: the state between two snippets is the merged read so far, merge_flag, and
+// whether the early return of merger.py:195-200 has been taken.
+struct RvMerger {
+  Aligner al;
+  int overlap = 25;
+  bool started = false, merge_flag = false, stopped = false;
+  std::string seq;
+  std::vector<float> lg;
+  std::string m_seq;
+  std::vector<float> m_lg;
+
+  int append(const uint8_t* bases, const float* probs, const int32_t* lengths, int64_t stride, int32_t n_chunks) {
+    for (int i = 0; i < n_chunks; ++i) if (lengths[i] < 0 || lengths[i] > stride) return RV_MERGE_EINVAL;
+    for (int i = 0; i < n_chunks; ++i) {
+      const char* sa = (const char*)bases + (size_t)i * stride;
+      const float* la = probs + (size_t)i * stride;
+      const int n = lengths[i];
+      if (!started) { seq.assign(sa, n); lg.assign(la, la + n); started = true; continue; }   // nuc_pred_snippets[0]
+      if (stopped) break;
+      const int n1 = (int)std::min<size_t>(seq.size(), overlap);      // seq_merged[-overlap:]
+      const int n2 = std::min(n, overlap);                             // seq_appended[:overlap]
+      const char* s1 = seq.data() + seq.size() - n1;
+      const float* l1 = lg.data() + lg.size() - n1;
+      if (al.sc.matrix) {
+        for (int k = 0; k < n1; ++k) if (base_index(s1[k]) < 0) return RV_MERGE_EALPHABET;
+        for (int k = 0; k < n2; ++k) if (base_index(sa[k]) < 0) return RV_MERGE_EALPHABET;
+      }
+      Aligned r;
+      if (!al.align(s1, n1, sa, n2, &r)) {                             // merger.py:181-200
+        if (!merge_flag) { seq.assign(sa, n); lg.assign(la, la + n); continue; }
+        stopped = true;
+        break;
+      }
+      merge_flag = true;
+      // align_logits + SingleMergerByLogits (merger.py:9-23, 88-119)
+      m_seq.clear(); m_lg.clear();
+      int i1 = 0, i2 = 0;
+      for (size_t c = 0; c < r.a.size(); ++c) {
+        const char c1 = r.a[c], c2 = r.b[c];
+        const float v1 = c1 == '-' ? -1.f : l1[i1++];
+        const float v2 = c2 == '-' ? -1.f : la[i2++];
+        if (c1 == '-') { m_seq.push_back(c2); m_lg.push_back(v2); }
+        else if (c2 == '-') { m_seq.push_back(c1); m_lg.push_back(v1); }
+        else if (v2 > v1) { m_seq.push_back(c2); m_lg.push_back(v2); }
+        else { m_seq.push_back(c1); m_lg.push_back(v1); }
+      }
+      // seq_merged[:-overlap] + merged + seq_appended[overlap:]   (merger.py:236-245)
+      seq.resize(seq.size() - n1); lg.resize(lg.size() - n1);
+      seq.append(m_seq); lg.insert(lg.end(), m_lg.begin(), m_lg.end());
+      if (n > overlap) { seq.append(sa + overlap, n - overlap); lg.insert(lg.end(), la + overlap, la + n); }
+    }
+    return 0;
+  }
+};
+
+extern "C" {
+
+int rv_merger_create(int32_t scores_id, int32_t overlap, rv_merger* out) {
+  if (!out || overlap < 1) return RV_MERGE_EINVAL;
+  RvMerger* m = new RvMerger();
+  if (!score_set(scores_id, &m->al.sc)) { delete m; return RV_MERGE_EINVAL; }
+  m->overlap = overlap;
+  *out = m;
+  return 0;
+}
+
+void rv_merger_destroy(rv_merger m) { delete m; }
+
+int rv_merger_append(rv_merger m, const uint8_t* bases, const float* probs, const int32_t* lengths, int64_t stride,
+                     int32_t n_chunks) {
+  if (!m || n_chunks < 0 || stride < 0 || (n_chunks && (!bases || !probs || !lengths))) return RV_MERGE_EINVAL;
+  return m->append(bases, probs, lengths, stride, n_chunks);
+}
+
+int rv_merger_result(rv_merger m, uint8_t* out_seq, float* out_probs, int64_t out_cap, int64_t* out_len) {
+  if (!m || !out_len) return RV_MERGE_EINVAL;
+  *out_len = (int64_t)m->seq.size();
+  if ((int64_t)m->seq.size() > out_cap) return RV_MERGE_ESPACE;
+  if (!m->seq.empty()) {
+    if (!out_seq || !out_probs) return RV_MERGE_ESPACE;
+    memcpy(out_seq, m->seq.data(), m->seq.size());
+    memcpy(out_probs, m->lg.data(), m->lg.size() * sizeof(float));
+  }
+  return 0;
+}
+
+int rv_merge_calls(const uint8_t* bases, const float* probs, const int32_t* lengths, int64_t stride, int32_t n_chunks,
+                   int32_t scores_id, int32_t overlap, uint8_t* out_seq, float* out_probs, int64_t out_cap, int64_t* out_len) {
+  if (n_chunks < 1 || !bases || !probs || !lengths || !out_len || overlap < 1 || stride < 0) return RV_MERGE_EINVAL;
+  RvMerger m;
+  if (!score_set(scores_id, &m.al.sc)) return RV_MERGE_EINVAL;
+  m.overlap = overlap;
+  const int rc = m.append(bases, probs, lengths, stride, n_chunks);
+  if (rc != 0) return rc;
+  return rv_merger_result(&m, out_seq, out_probs, out_cap, out_len);
+}
+
+}  // extern "C"

@@ -2,9 +2,8 @@
 (/root/reference/ravvent_performance_evaluator.py:24-87): same call sequence -- slabs of
 `chunk_size` chunks -> `beam_search_prediction(beam_width=5)` -> per-base probabilities and
 strings -- and the same result-dict keys and phase timers.  The reference file itself imports
-TensorFlow and Biopython and cannot run here; read-level merging
-(`merger.py`) is a host-side "next" row and is reported as `t_merge = 0` with the per-chunk
-calls returned un-merged.
+TensorFlow and Biopython and cannot run here.  Read-level merging is the C++
+merger behind `merger.Merger` (csrc/merger.cpp; `t_merge`, ravvent_performance_evaluator.py:73-75).
 """
 from __future__ import annotations
 
@@ -12,15 +11,19 @@ from timeit import default_timer as timer
 
 import numpy as np
 
-from . import utils
+from . import merger, utils
 
 
 class PerformanceEvaluator:
-    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False):
+    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False, pipelined_merge: bool = False):
         self.basecaller = basecaller
         self.stride = stride           # ravvent_performance_evaluator.py:16
         # True: strings + per-base probabilities come straight from the device (rv_beam_search_calls)
         self.fused_postprocessing = fused_postprocessing
+        self.merger = merger.Merger()  # ravvent_performance_evaluator.py:17
+        # True: slab k is stitched on a host thread (rv_merger_append) while the GPU decodes slab k+1; implies the
+        # fused post-processing.  t_merge is then the part of the merge the GPU work did not hide.
+        self.pipelined_merge = pipelined_merge
 
     @staticmethod
     def _split_into_chunks(arr, def_chunk_size):
@@ -62,6 +65,9 @@ class PerformanceEvaluator:
         t_data_loading = timer() - start
         nuc_preds = []
         t_predicting = t_postprocessing = 0.0
+        if self.pipelined_merge:
+            return self._run_pipelined(data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width,
+                                       t_data_loading)
         for data in data_chunks:
             start = timer()
             input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
@@ -79,7 +85,9 @@ class PerformanceEvaluator:
             seqs = self.basecaller.tokens_to_nuc_sequences(pred_tokens)
             nuc_preds.extend((seq, list(sc[:len(seq)])) for seq, sc in zip(seqs, scores))
             t_postprocessing += timer() - start
-        t_merge = 0.0
+        start = timer()                # ravvent_performance_evaluator.py:73-75
+        merged_seq = self.merger.merge([merger.SeqLogitsPair(seq, lg) for seq, lg in nuc_preds]).seq if nuc_preds else ""
+        t_merge = timer() - start
         n_chunks = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
         if bases_num is None:
             bases_num = n_chunks * self.stride
@@ -89,5 +97,40 @@ class PerformanceEvaluator:
             "t_postprocessing": t_postprocessing, "t_merge": t_merge,
             "total": t_data_loading + t_predicting + t_postprocessing + t_merge,
             "total_processing": t_predicting + t_postprocessing + t_merge,
-            "nuc_preds": nuc_preds,
+            "nuc_preds": nuc_preds, "merged_seq": merged_seq,
+        }
+
+    def _run_pipelined(self, data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width, t_data_loading):
+        from concurrent.futures import ThreadPoolExecutor
+        sm = merger.StreamingMerger(self.merger.scores_id, self.merger.overlap_seq_len)
+        kept, pending = [], []
+        t_predicting = 0.0
+        with ThreadPoolExecutor(max_workers=1) as pool:          # one worker: slabs are appended in read order
+            for data in data_chunks:
+                start = timer()
+                input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
+                arrays = self.basecaller.beam_search_call_arrays(input_data, beam_width=beam_width,
+                                                                 max_output_len=target_data.shape[1])
+                t_predicting += timer() - start
+                kept.append(arrays)
+                pending.append(pool.submit(sm.append, *arrays))
+            start = timer()
+            for f in pending:
+                f.result()
+            merged_seq, _ = sm.result()
+            t_merge = timer() - start
+        sm.close()
+        nuc_preds = []                                           # per-chunk view for callers that want it (untimed)
+        for bases, probs, lens in kept:
+            flat, steps = bases.tobytes(), bases.shape[1]
+            nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), list(probs[i, :int(n)]))
+                             for i, n in enumerate(lens))
+        n_chunks = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
+        if bases_num is None:
+            bases_num = n_chunks * self.stride
+        return {
+            "bases_num": int(bases_num), "samples_num": samples_num, "chunks_num": n_chunks,
+            "t_data_loading": t_data_loading, "t_predicting": t_predicting, "t_postprocessing": 0.0, "t_merge": t_merge,
+            "total": t_data_loading + t_predicting + t_merge, "total_processing": t_predicting + t_merge,
+            "nuc_preds": nuc_preds, "merged_seq": merged_seq,
         }

@@ -87,7 +87,7 @@ def test_shard_ranges_cover_contiguously(rv):
 def test_library_exports_every_declared_symbol(rv):
     """The C-ABI library loads on a GPU-less host and exports exactly what the header declares;
     no compute entry point is called here."""
-    hdr = open(os.path.join(ROOT, "include", "ravvent_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("ravvent_hip.h", "ravvent_merge.h"))
     declared = set(re.findall(r"\b(rv_\w+)\s*\(", hdr)) - {"rv_handle"}
     lib = rv._capi.load_library()
     assert declared == {n for n, _, _ in rv._capi.SYMBOLS}
