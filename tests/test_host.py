@@ -114,3 +114,30 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "ravvent_oracle" not in src, f
+
+
+def test_mapping_evaluator_files_and_paf(rv, tmp_path):
+    """ravvent_mapping_evaluator.py:74-108,130-167 without minimap2: FASTA/FASTQ writers, PAF identity, totals."""
+    import json
+    import ravvent_basecaller_amd.mapping_evaluator as me
+    ev = me.MappingEvaluator(workdir=str(tmp_path))
+    ev._create_fasta("ACGTACGTACGTAA", tmp_path / "r.fasta")
+    ev._create_fastq("ACGTTT", tmp_path / "p.fastq")
+    assert (tmp_path / "r.fasta").read_text() == ">ACGTACGTAC\nACGTACGTACGTAA"
+    assert (tmp_path / "p.fastq").read_text() == "@ACGTTT\nACGTTT\n+\n!!!!!!"
+    paf = tmp_path / "m.paf"
+    paf.write_text("q\t900\t0\t400\t+\tt\t1000\t10\t420\t380\t410\t60\ttp:A:P\n"
+                   "q\t900\t400\t900\t+\tt\t1000\t500\t990\t450\t500\t60\n"
+                   "short\tline\n")
+    r = ev._read_mapping_identity(paf)
+    assert r == {"read_length": 900, "matches": 830, "total_block_len": 910, "identity": 830 / 910}
+    (tmp_path / "empty.paf").write_text("")
+    assert ev._read_mapping_identity(tmp_path / "empty.paf")["identity"] == 0.0
+    res = [dict(r, ref_length=1000), {"read_length": 0, "matches": 0, "total_block_len": 0, "identity": 0.0, "ref_length": 500}]
+    (tmp_path / "res.json").write_text(json.dumps(res))
+    tot, valid, invalid = ev.compute_total_results(tmp_path / "res.json")
+    assert (tot, valid, invalid) == (round(830 / 910 * 1000 / 1500 * 100, 3), round(830 / 910 * 100, 3), 50.0)
+    import shutil
+    if shutil.which("minimap2") is None:
+        with pytest.raises(RuntimeError, match="minimap2"):
+            ev.map_read("ACGT" * 10, "ACGT" * 9)
