@@ -117,7 +117,8 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       The step_ids / parent_ids / step_scores taps of a chunk then end at its own last
  *                       step instead of the slab's),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around
- *                       the graph as a whole; 2: no graph, events around every kernel). */
+ *                       the graph as a whole; 2: no graph, events around every kernel; 3: events around the decode
+ *                       launch only -- the persistent decode kernel or the decode graph). */
 int rv_set_option(rv_handle h, const char* key, int32_t value);
 
 /* Debug taps of the LAST call, copied to host as fp32 (bool/int tensors are converted):

@@ -1,0 +1,21 @@
+"""Diagnostic: wall time per C3 slab (device-resident inputs) with the library's profiling events off / on."""
+import gc, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import ravvent_basecaller_amd as rv
+B, T_r, T_e, W, L = 256, 300, 30, 5, 48
+bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L)
+bc.init_random_weights(seed=22)
+raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=0)
+x = (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
+gc.disable()
+for prof in (0, 1, 0, 1):
+    bc.set_option("profile", prof)
+    for _ in range(5):
+        bc.beam_search_prediction(x, W, L)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(60):
+        t = time.perf_counter(); bc.beam_search_prediction(x, W, L); ts.append(time.perf_counter() - t)
+    ts = np.array(ts) * 1e3
+    print(f"profile={prof}: mean {ts.mean():.3f} ms  median {np.median(ts):.3f}  min {ts.min():.3f}  max {ts.max():.3f}  >2.8ms: {(ts > 2.8).sum()}")
