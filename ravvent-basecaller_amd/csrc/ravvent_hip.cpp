@@ -49,7 +49,7 @@ struct RvContext {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int opt_att_nt = 0;
-  int opt_side_ev = 0;
+  int opt_side_ev = 1;                      // event chain on a side stream under the raw in-projection GEMM
   int opt_persist = 1;                      // whole beam-search loop in one launch, attention memory register-resident
   int* d_chunk_steps = nullptr;
   int lpersist = 0;
@@ -206,10 +206,11 @@ int pick_rows_per_block(int B) {
 }
 
 // Encoder.call for one encoder (basecaller.py:48-59) writing into enc_out at time offset t_off.
-void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s) {
+void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s,
+                 int l_begin = 0, int l_end = 1 << 30) {
   const int depth = h->cfg.enc_depth;
   const int bt = pick_rows_per_block(B);
-  for (int l = 0; l < depth; ++l) {
+  for (int l = std::max(l_begin, 0); l < std::min(depth, l_end); ++l) {
     const bool last = l == depth - 1;
     float* out = last ? h->enc_out : h->act[e][l & 1];
     RecArgs a{};
@@ -309,20 +310,23 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
 
   // ---- _encode_input (basecaller.py:395-416)
   { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
-  // The two encoders are independent until the time-axis concat (basecaller.py:400-405).  Running the
-  // short event chain on a side stream under the raw chain was measured neutral-to-negative at
-  // B = 256 (every recurrence workgroup needs a whole CU), so it is off unless asked for.
-  const bool side_ev = use_raw && use_ev && h->opt_side_ev;
-  hipStream_t sev = side_ev ? h->side[0] : s;
+  // The two encoders are independent until the time-axis concat (basecaller.py:400-405).
+  const bool side_ev = use_raw && use_ev && h->opt_side_ev && c.enc_depth > 1;
   if (side_ev) {
+    // raw layer 0 alone (every recurrence workgroup needs a whole CU); then the short event chain on a side stream
+    // UNDER the raw encoder's input-projection GEMM: a recurrence workgroup (2 x 168 VGPRs per SIMD, VALU-bound) and a
+    // GEMM workgroup (144 registers, MFMA-bound) fit on one CU together.
+    hipStream_t sev = h->side[0];
+    run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 0, 1);
     HIPCHK(h, hipEventRecord(h->ev_fork, s));
     HIPCHK(h, hipStreamWaitEvent(sev, h->ev_fork, 0));
-  }
-  if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, sev);
-  if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
-  if (side_ev) {
+    run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, sev);
+    run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 1);
     HIPCHK(h, hipEventRecord(h->ev_join[0], sev));
     HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
+  } else {
+    if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, s);
+    if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
   }
 
   // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem.  The single-pass Luong
@@ -573,7 +577,11 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &d.S_dev, 8));
   TRY(dalloc(h, &h->d_chunk_steps, (size_t)c.max_batch));
   for (int g = 0; g < 3; ++g) {
-    HIPTRY(hipStreamCreateWithFlags(&h->side[g], hipStreamNonBlocking));
+    {   // side streams get the highest priority: their few workgroups should take CU slots as soon as they free up
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIPTRY(hipStreamCreateWithPriority(&h->side[g], hipStreamNonBlocking, hi));
+    }
     HIPTRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
   }
   HIPTRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

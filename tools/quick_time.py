@@ -19,3 +19,13 @@ for prof in (0, 1, 0, 1):
         t = time.perf_counter(); bc.beam_search_prediction(x, W, L); ts.append(time.perf_counter() - t)
     ts = np.array(ts) * 1e3
     print(f"profile={prof}: mean {ts.mean():.3f} ms  median {np.median(ts):.3f}  min {ts.min():.3f}  max {ts.max():.3f}  >2.8ms: {(ts > 2.8).sum()}")
+bc.set_option("profile", 0)
+for side in (0, 1, 0, 1):
+    bc.set_option("concurrent_encoders", side)
+    for _ in range(5):
+        bc.beam_search_prediction(x, W, L)
+    ts = []
+    for _ in range(60):
+        t = time.perf_counter(); bc.beam_search_prediction(x, W, L); ts.append(time.perf_counter() - t)
+    ts = np.array(ts) * 1e3
+    print(f"concurrent_encoders={side}: mean {ts.mean():.3f} ms  median {np.median(ts):.3f}  min {ts.min():.3f}")
