@@ -18,6 +18,7 @@ struct RecArgs {
   const float* W[2];     // F>0: input kernel [F,512] per direction
   const float* bias[2];  // F>0: [512] per direction
   const float* U[2];     // recurrent kernel [128,512] per direction
+  const float* Wp[2];    // fused-projection kernel only: input kernel [256,512] as MFMA B fragments [32 tiles][16 k-groups][64 lanes][4]
   const float* h0[2];    // initial states [B,128] or nullptr (zeros)
   const float* c0[2];
   float* hT[2];          // final states [B,128]
@@ -25,9 +26,14 @@ struct RecArgs {
   float* out;            // [B,out_T,256]; direction d writes columns [128d,128d+128) at time out_t0+t
   int out_T, out_t0;
   int B, T;
+  int dbg_role;          // timing probe only (RV_DBG_ROLE): 1 = projection waves skip their math, 2 = recurrence waves skip theirs
 };
 // F in {0,1,5}; rows_per_block in {1,2,4,8}
 void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s);
+// layers >= 1 with x . W + b computed inside the kernel (MFMA waves beside the recurrence waves): a.x = [B,T,256] activations,
+// a.Wp / a.bias per direction
+void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
+void configure_rec_kernels();
 
 // ---------------------------------------------------------------- K0/K2: fp32 MFMA GEMM
 struct GemmArgs {

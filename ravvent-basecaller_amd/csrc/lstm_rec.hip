@@ -170,6 +170,234 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Layers >= 1 with the input projection computed IN the recurrence kernel, on the matrix pipe.
+// The standalone K0 GEMM leaves the VALU idle and the recurrence leaves the MFMA pipe idle; here one
+// 768-thread workgroup holds both: waves 0-7 are the recurrence above (same registers, same math),
+// waves 8-11 (one per SIMD; 3 x 168 VGPRs fit the 512-register file) project the NEXT block of
+// TBK = 16/BT timesteps of the workgroup's own BT chunks, x[16 rows, 256] . W[256, 512] + b, with
+// v_mfma_f32_16x16x4_f32, and hand it over through LDS -- no inter-workgroup synchronisation, no
+// pre-projected tensor in HBM.  Per block: activations of block n+2 are fetched from global into a
+// double-buffered, fragment-ordered LDS image; every projection wave finishes 8 of the 32 column
+// tiles, one (tile, K-half) unit per chunk per step, reading its B fragments as one float4 per lane
+// per 4 MFMAs from a weight image pre-arranged at load time (Wp: [tile][k-group][lane][4]).
+template <int BT>
+__global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
+  constexpr int TBK = 16 / BT;                 // timesteps per projected block (16 MFMA rows)
+  extern __shared__ __align__(16) float smem[];
+  float* hs = smem;                            // [2][BT][128]
+  float* xwb = hs + 2 * BT * RV_U;             // [2][16 rows][512]   projected inputs, row = s_local*BT + r
+  float* xa = xwb + 2 * 16 * RV_G;             // [2][16 k-groups][4 q][16 rows][4 i]  A fragments: lane (q, row) reads one float4
+
+  const int tid = threadIdx.x;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * BT;
+  const int T = a.T;
+  const int nblk = (T + TBK - 1) / TBK;
+  const bool proj = tid >= 512;
+
+  // stage of A rows of block `blk` (walk order) into xa[blk & 1]; 256 threads, 4 float4 each
+  const int p = tid - 512;
+  auto a_load = [&](int blk, float4* v) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int idx = p + 256 * f, rho = idx >> 6, k4 = idx & 63;
+      const int s = min(blk * TBK + rho / BT, T - 1), r = rho % BT;
+      const int t = dir ? T - 1 - s : s;
+      const int b = min(b0 + r, a.B - 1);
+      v[f] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * T + t) * RV_E + 4 * k4);
+    }
+  };
+  auto a_store = [&](int blk, const float4* v) {
+    float* dst = xa + (blk & 1) * (16 * 16 * 16);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int idx = p + 256 * f, rho = idx >> 6, k4 = idx & 63;
+      float* q0 = dst + (k4 >> 2) * 256 + rho * 4 + (k4 & 3);            // [g][q][rho][i]: g = k/16, i = (k%16)/4, q = k%4
+      q0[0] = v[f].x; q0[64] = v[f].y; q0[128] = v[f].z; q0[192] = v[f].w;   // q = element index; a lane's float4 = its 4 k-steps
+    }
+  };
+
+  // The two roles run separate loops with the same number of workgroup barriers (T + TBK step barriers after one
+  // prologue barrier): s_barrier counts arriving waves, not program counters, and separate loops keep the register
+  // allocation of the recurrence (128 VGPRs of U) apart from the projection's fragments.
+  if (proj) {
+    const int lane = tid & 63, pw = p >> 6;             // projection wave 0..3 owns column tiles 8 pw .. 8 pw + 7
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float4 av[4];                                       // activations of a later block in flight
+    a_load(0, av); a_store(0, av);
+    if (nblk > 1) { a_load(1, av); a_store(1, av); }
+    __syncthreads();
+    // One projection "unit" = (column tile, K half): 8 k-groups = 32 MFMAs.  A block needs 16 units per wave;
+    // BT of them run per step, so block n+1 is complete exactly when the recurrence finishes block n.
+    // This wave is alone with its MFMAs on its SIMD, so nothing hides its load latency: the B fragments of the
+    // NEXT unit are requested before the MFMAs of the current one (the unit -> address map does not depend on
+    // the block), the A fragments are read from LDS in one batch at the start of a unit.
+    auto b_issue = [&](int unit, float4* bf) {
+      const int nt = 8 * pw + ((unit & 15) >> 1), kh = unit & 1;
+      const float* bp = a.Wp[dir] + (((size_t)nt * 16 + 8 * kh) * 64 + lane) * 4;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) bf[g] = *reinterpret_cast<const float4*>(bp + (size_t)g * 256);
+    };
+    float bias8[8];                                     // bias of this wave's 8 column tiles (col = 16 nt + lane%16)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias8[i] = a.bias[dir][16 * (8 * pw + i) + (lane & 15)];
+    auto a_issue = [&](int blk, int unit, float4* af) {
+      const float* ap = xa + (blk & 1) * (16 * 16 * 16) + (8 * (unit & 1)) * 256 + lane * 4;   // [g][q = lane/16][rho = lane%16][i]
+#pragma unroll
+      for (int g = 0; g < 8; ++g) af[g] = *reinterpret_cast<const float4*>(ap + g * 256);
+    };
+    auto proj_unit = [&](int blk, int unit, const float4* bf, const float4* af) {
+      const int nt = 8 * pw + (unit >> 1), kh = unit & 1;
+      if (kh == 0) { acc0 = f4v{0.f, 0.f, 0.f, 0.f}; acc1 = f4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].x, bf[g].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].y, bf[g].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].z, bf[g].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].w, bf[g].w, acc1, 0, 0, 0);
+      }
+      if (kh == 1) {                                     // tile done: + bias -> LDS (C/D map: col = lane%16, row = 4*(lane/16)+i)
+        const int col = 16 * nt + (lane & 15);
+        float bb = bias8[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) bb = (unit >> 1) == i ? bias8[i] : bb;
+        float* dst = xwb + (blk & 1) * (16 * RV_G) + (4 * (lane >> 4)) * RV_G + col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * RV_G] = (acc0[i] + acc1[i]) + bb;
+      }
+    };
+    float4 bfa[8], bfb[8], afa[8], afb[8];
+    b_issue(0, bfa);
+    for (int s = -TBK; s < T; ++s) {
+      const int blk = s >= 0 ? s / TBK : -1;            // block the recurrence is in (-1: warm-up while block 0 is projected)
+      const int sl = s - blk * TBK;                     // step inside the block, 0..TBK-1
+      const int nb = blk + 1;                           // block being projected
+      if (nb < nblk && a.dbg_role != 1) {
+        // A fragments are prefetched one unit ahead inside a block; the first unit of a block reads them after
+        // the barrier that published the block's LDS image.
+        if (BT == 1) {                                   // one unit per step: the fragment buffers rotate through registers
+          if (sl == 0) a_issue(nb, 0, afa);
+          b_issue(sl + 1, bfb);
+          if (sl + 1 < 16) a_issue(nb, sl + 1, afb);
+          proj_unit(nb, sl, bfa, afa);
+#pragma unroll
+          for (int g = 0; g < 8; ++g) { bfa[g] = bfb[g]; afa[g] = afb[g]; }
+        } else {
+          if (sl == 0) a_issue(nb, 0, afa);
+#pragma unroll
+          for (int u = 0; u < BT; u += 2) {              // BT is even: units alternate between the two fragment buffers
+            const int u0 = sl * BT + u;
+            b_issue(u0 + 1, bfb); a_issue(nb, u0 + 1, afb);
+            proj_unit(nb, u0, bfa, afa);
+            b_issue(u0 + 2, bfa);
+            if (u0 + 2 < 16) a_issue(nb, u0 + 2, afa);
+            proj_unit(nb, u0 + 1, bfb, afb);
+          }
+        }
+      }
+      // activations of block nb+1: fetched at the first step of this block, stored at its last step (that LDS image
+      // was last read while block nb-1 was projected)
+      if (nb >= 1 && nb + 1 < nblk) {
+        if (sl == 0) a_load(nb + 1, av);
+        if (sl == TBK - 1) a_store(nb + 1, av);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- recurrence role (the loop body is k_lstm_rec<BT, 0>'s, with x.W + b read from LDS)
+  const int j = tid >> 2, kq = tid & 3;
+  f2 u01[32], u23[32];
+  float c[BT], hlast[BT];
+  const float am = kq == 2 ? 2.f : 1.f;
+  {
+    const float* Ud = a.U[dir] + (32 * kq) * RV_G + j;
+    const int g0 = kq * RV_U, g1 = ((kq + 1) & 3) * RV_U, g2 = ((kq + 2) & 3) * RV_U, g3 = ((kq + 3) & 3) * RV_U;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      u01[i] = f2{Ud[i * RV_G + g0], Ud[i * RV_G + g1]};
+      u23[i] = f2{Ud[i * RV_G + g2], Ud[i * RV_G + g3]};
+    }
+#pragma unroll
+    for (int r = 0; r < BT; ++r) {
+      const int b = min(b0 + r, a.B - 1);
+      c[r] = a.c0[dir] ? a.c0[dir][(size_t)b * RV_U + j] : 0.f;
+      hlast[r] = 0.f;
+      if (kq == 0) hs[r * RV_U + j] = a.h0[dir] ? a.h0[dir][(size_t)b * RV_U + j] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int s = -TBK; s < 0; ++s) __syncthreads();       // block 0 is being projected
+  int cur = 0;
+  for (int s = 0; s < T; ++s) {
+    if (a.dbg_role == 2) { __syncthreads(); continue; }
+    const int blk = s / TBK, sl = s - blk * TBK;
+    const int t = dir ? T - 1 - s : s;
+    const float* hc = hs + cur * BT * RV_U;
+    float* hn = hs + (cur ^ 1) * BT * RV_U;
+    const float* xrow = xwb + (blk & 1) * (16 * RV_G) + (sl * BT) * RV_G + kq * RV_U + j;
+    float z[BT];
+#pragma unroll
+    for (int r = 0; r < BT; ++r) {
+      // plain v_fma_f32 here: packed f32 VALU shares the datapath the fp32 MFMAs of the projection waves run on
+      // (a v_pk_fma_f32 beside MFMAs costs ~22 cycles more than two v_fma_f32), plain FMAs issue in the MFMA's shadow
+      float s0 = xrow[r * RV_G], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      const float4* hp = reinterpret_cast<const float4*>(hc + r * RV_U + 32 * kq);
+#pragma unroll
+      for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 hv = hp[i4];
+#define RV_FMA4(H, I) s0 = __builtin_fmaf(H, u01[I].x, s0); s1 = __builtin_fmaf(H, u01[I].y, s1); \
+                      s2 = __builtin_fmaf(H, u23[I].x, s2); s3 = __builtin_fmaf(H, u23[I].y, s3);
+        RV_FMA4(hv.x, 4 * i4 + 0) RV_FMA4(hv.y, 4 * i4 + 1) RV_FMA4(hv.z, 4 * i4 + 2) RV_FMA4(hv.w, 4 * i4 + 3)
+#undef RV_FMA4
+      }
+      const f2 a01 = f2{s0, s1}, a23 = f2{s2, s3};
+      float zz = a01.x + quad_perm<0x39>(a23.y);
+      zz += quad_perm<0x4E>(a23.x);
+      zz += quad_perm<0x93>(a01.y);
+      z[r] = zz;
+    }
+#pragma unroll
+    for (int r = 0; r < BT; ++r) {
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-am * z[r]));
+      const float act = fmaf(sg, am, 1.0f - am);
+      const float ig = quad_perm<0x00>(act), fg = quad_perm<0x55>(act);
+      const float gg = quad_perm<0xAA>(act), og = quad_perm<0xFF>(act);
+      c[r] = fmaf(fg, c[r], ig * gg);
+      hlast[r] = og * rv_tanh(c[r]);
+    }
+    if (kq == 0) {
+#pragma unroll
+      for (int r = 0; r < BT; ++r) {
+        hn[r * RV_U + j] = hlast[r];
+        if (b0 + r < a.B)
+          a.out[((size_t)(b0 + r) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + j] = hlast[r];
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (kq == 0) {
+#pragma unroll
+    for (int r = 0; r < BT; ++r)
+      if (b0 + r < a.B) {
+        a.hT[dir][(size_t)(b0 + r) * RV_U + j] = hlast[r];
+        a.cT[dir][(size_t)(b0 + r) * RV_U + j] = c[r];
+      }
+  }
+}
+
+template <int BT>
+void launch_proj(const RecArgs& a, hipStream_t s) {
+  dim3 grid((a.B + BT - 1) / BT, 2);
+  const size_t shm = sizeof(float) * (2 * BT * RV_U + 2 * 16 * RV_G + 2 * 16 * 16 * 16);
+  hipLaunchKernelGGL((k_lstm_rec_proj<BT>), grid, dim3(768), shm, s, a);
+}
+
 template <int BT, int F>
 void launch_one(const RecArgs& a, hipStream_t s) {
   dim3 grid((a.B + BT - 1) / BT, 2);
@@ -188,6 +416,22 @@ void launch_f(const RecArgs& a, int bt, hipStream_t s) {
 }
 
 }  // namespace
+
+void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s) {
+  switch (rows_per_block) {
+    case 1: launch_proj<1>(a, s); break;
+    case 2: launch_proj<2>(a, s); break;
+    case 4: launch_proj<4>(a, s); break;
+    default: launch_proj<8>(a, s); break;
+  }
+}
+void configure_rec_kernels() {
+  const int shm = (int)(sizeof(float) * (2 * 8 * RV_U + 2 * 16 * RV_G + 2 * 16 * 16 * 16));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<4>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<8>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+}
 
 void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s) {
   if (F == 0) launch_f<0>(a, rows_per_block, s);

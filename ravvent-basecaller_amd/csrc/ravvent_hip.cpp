@@ -55,6 +55,9 @@ struct RvContext {
   int lpersist = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0, lsplit = 1;
+  float* d_Wp = nullptr;                    // derived: input kernels of encoder layers >= 1 as MFMA B fragments, [enc][layer-1][dir][131072]
+  int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
+  int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
@@ -232,6 +235,17 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       launch_lstm_rec(a, F, bt, s);
     } else {
       const float* in = h->act[e][(l - 1) & 1];
+      if (h->opt_fuse) {   // x . W + b on the matrix pipe inside the recurrence kernel: no K0 launch, no xw tensor
+        a.x = in;
+        a.dbg_role = h->dbg_role;
+        for (int dr = 0; dr < 2; ++dr) {
+          a.Wp[dr] = h->d_Wp + ((size_t)(e * (depth - 1) + (l - 1)) * 2 + dr) * RV_E * RV_G;
+          a.bias[dr] = h->enc[e][l][dr].b;
+        }
+        Scope sc(h, e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p", s);
+        launch_lstm_rec_proj(a, bt, s);
+        continue;
+      }
       {   // both directions in ONE launch (same A): 2x the workgroups -> less round quantisation
         GemmArgs g{};
         g.A = in; g.lda = RV_E; g.ldb = RV_G; g.ldc = 2 * RV_G;
@@ -311,7 +325,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   // ---- _encode_input (basecaller.py:395-416)
   { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
   // The two encoders are independent until the time-axis concat (basecaller.py:400-405).
-  const bool side_ev = use_raw && use_ev && h->opt_side_ev && c.enc_depth > 1;
+  const bool side_ev = use_raw && use_ev && h->opt_side_ev && c.enc_depth > 1 && !h->opt_fuse;   // (nothing MFMA-bound to hide under once the projection is fused)
   if (side_ev) {
     // raw layer 0 alone (every recurrence workgroup needs a whole CU); then the short event chain on a side stream
     // UNDER the raw encoder's input-projection GEMM: a recurrence workgroup (2 x 168 VGPRs per SIMD, VALU-bound) and a
@@ -531,12 +545,15 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   HIPTRY(hipSetDevice(c.device));
   HIPTRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   configure_decode_kernels();
+  configure_rec_kernels();
   const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
   const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
   const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
+  if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
   TRY(dalloc(h, &h->d_raw, B * Tr));
@@ -639,6 +656,20 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
         for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
       HIPCHK(h, hipMemcpy(h->d_WcatT + (size_t)l * RV_G * RV_E, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    // encoder layers >= 1: W [256][512] -> [32 column tiles][16 k-groups][64 lanes][4]: lane (q = lane/16, col = lane%16)
+    // of tile nt finds W[16 g + 4 i + q][16 nt + col] for its 4 MFMAs i of k-group g in one float4 (lstm_rec.hip)
+    for (int e = 0; e < 2; ++e)
+      for (int l = 1; l < h->cfg.enc_depth; ++l)
+        for (int dr = 0; dr < 2; ++dr) {
+          const size_t off = (size_t)(h->enc[e][l][dr].W - h->d_w);
+          for (int nt = 0; nt < 32; ++nt)
+            for (int g = 0; g < 16; ++g)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int i = 0; i < 4; ++i)
+                  t[(((size_t)nt * 16 + g) * 64 + ln) * 4 + i] = blob[off + (size_t)(16 * g + 4 * i + (ln >> 4)) * RV_G + 16 * nt + (ln & 15)];
+          float* dst = h->d_Wp + ((size_t)(e * (h->cfg.enc_depth - 1) + (l - 1)) * 2 + dr) * RV_E * RV_G;
+          HIPCHK(h, hipMemcpy(dst, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
     std::vector<float> m((size_t)RV_U * RV_E);
     for (int i = 0; i < RV_E; ++i)
@@ -680,6 +711,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
   else if (!strcmp(key, "persistent_decode")) h->opt_persist = value != 0;
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
+  else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");
     h->opt_att_nt = value;

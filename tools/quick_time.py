@@ -29,3 +29,20 @@ for side in (0, 1, 0, 1):
         t = time.perf_counter(); bc.beam_search_prediction(x, W, L); ts.append(time.perf_counter() - t)
     ts = np.array(ts) * 1e3
     print(f"concurrent_encoders={side}: mean {ts.mean():.3f} ms  median {np.median(ts):.3f}  min {ts.min():.3f}")
+bc.set_option("fused_projection", 0)
+ref = bc.beam_search_prediction(x, W, L)
+ref_enc = bc.get_tensor("enc_output")
+for fuse in (0, 1, 0, 1):
+    bc.set_option("fused_projection", fuse)
+    for _ in range(5):
+        out = bc.beam_search_prediction(x, W, L)
+    enc = bc.get_tensor("enc_output")
+    print("   max |enc - enc_unfused|", float(np.abs(enc - ref_enc).max()), "tokens equal", bool((out[0] == ref[0]).all()))
+    ts = []
+    for _ in range(60):
+        t = time.perf_counter(); bc.beam_search_prediction(x, W, L); ts.append(time.perf_counter() - t)
+    ts = np.array(ts) * 1e3
+    print(f"fused_projection={fuse}: mean {ts.mean():.3f} ms  median {np.median(ts):.3f}  min {ts.min():.3f}")
+bc.set_option("profile", 1); bc.reset_profile()
+for _ in range(10): bc.beam_search_prediction(x, W, L)
+print({k: round(v[0] / v[1], 4) for k, v in bc.profile().items()})
