@@ -185,10 +185,12 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
 template <int BT>
 __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
   constexpr int TBK = 16 / BT;                 // timesteps per projected block (16 MFMA rows)
+  constexpr int XG = 260;                      // k-group stride of the A image (256 + 4: the transposing stores hit 2 banks deep, not 16)
   extern __shared__ __align__(16) float smem[];
   float* hs = smem;                            // [2][BT][128]
   float* xwb = hs + 2 * BT * RV_U;             // [2][16 rows][512]   projected inputs, row = s_local*BT + r
-  float* xa = xwb + 2 * 16 * RV_G;             // [2][16 k-groups][4 q][16 rows][4 i]  A fragments: lane (q, row) reads one float4
+  float* bsm = xwb + 2 * 16 * RV_G;            // [512] bias of this direction
+  float* xa = bsm + RV_G;             // [2][16 k-groups][4 q][16 rows][4 i]  A fragments: lane (q, row) reads one float4
 
   const int tid = threadIdx.x;
   const int dir = blockIdx.y;
@@ -210,11 +212,11 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
     }
   };
   auto a_store = [&](int blk, const float4* v) {
-    float* dst = xa + (blk & 1) * (16 * 16 * 16);
+    float* dst = xa + (blk & 1) * (16 * XG);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int idx = p + 256 * f, rho = idx >> 6, k4 = idx & 63;
-      float* q0 = dst + (k4 >> 2) * 256 + rho * 4 + (k4 & 3);            // [g][q][rho][i]: g = k/16, i = (k%16)/4, q = k%4
+      float* q0 = dst + (k4 >> 2) * XG + rho * 4 + (k4 & 3);            // [g][q][rho][i]: g = k/16, i = (k%16)/4, q = k%4
       q0[0] = v[f].x; q0[64] = v[f].y; q0[128] = v[f].z; q0[192] = v[f].w;   // q = element index; a lane's float4 = its 4 k-steps
     }
   };
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
     float4 av[4];                                       // activations of a later block in flight
     a_load(0, av); a_store(0, av);
     if (nblk > 1) { a_load(1, av); a_store(1, av); }
+    bsm[p] = a.bias[dir][p]; bsm[p + 256] = a.bias[dir][p + 256];
     __syncthreads();
     // One projection "unit" = (column tile, K half): 8 k-groups = 32 MFMAs.  A block needs 16 units per wave;
     // BT of them run per step, so block n+1 is complete exactly when the recurrence finishes block n.
@@ -241,16 +244,20 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) bf[g] = *reinterpret_cast<const float4*>(bp + (size_t)g * 256);
     };
-    float bias8[8];                                     // bias of this wave's 8 column tiles (col = 16 nt + lane%16)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias8[i] = a.bias[dir][16 * (8 * pw + i) + (lane & 15)];
     auto a_issue = [&](int blk, int unit, float4* af) {
-      const float* ap = xa + (blk & 1) * (16 * 16 * 16) + (8 * (unit & 1)) * 256 + lane * 4;   // [g][q = lane/16][rho = lane%16][i]
+      const float* ap = xa + (blk & 1) * (16 * XG) + (8 * (unit & 1)) * XG + lane * 4;   // [g][q = lane/16][rho = lane%16][i]
 #pragma unroll
-      for (int g = 0; g < 8; ++g) af[g] = *reinterpret_cast<const float4*>(ap + g * 256);
+      for (int g = 0; g < 8; ++g) af[g] = *reinterpret_cast<const float4*>(ap + g * XG);
     };
-    auto proj_unit = [&](int blk, int unit, const float4* bf, const float4* af) {
+    // unit = request the NEXT unit's B fragments (global), read this unit's A fragments (LDS), then 32 MFMAs on the
+    // fragments requested one unit ago.  The scheduling fences keep the requests in front of the MFMAs: vmcnt retires in
+    // order, so waiting for this unit's fragments leaves the next unit's 8 loads in flight.
+    auto proj_unit = [&](int blk, int unit, const float4* bf, float4* bf_next) {
       const int nt = 8 * pw + (unit >> 1), kh = unit & 1;
+      b_issue(unit + 1, bf_next);
+      float4 af[8];
+      a_issue(blk, unit, af);
+      __builtin_amdgcn_sched_barrier(0);
       if (kh == 0) { acc0 = f4v{0.f, 0.f, 0.f, 0.f}; acc1 = f4v{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -259,42 +266,31 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].z, bf[g].z, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g].w, bf[g].w, acc1, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (kh == 1) {                                     // tile done: + bias -> LDS (C/D map: col = lane%16, row = 4*(lane/16)+i)
         const int col = 16 * nt + (lane & 15);
-        float bb = bias8[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) bb = (unit >> 1) == i ? bias8[i] : bb;
+        const float bb = bsm[col];
         float* dst = xwb + (blk & 1) * (16 * RV_G) + (4 * (lane >> 4)) * RV_G + col;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dst[i * RV_G] = (acc0[i] + acc1[i]) + bb;
       }
     };
-    float4 bfa[8], bfb[8], afa[8], afb[8];
+    float4 bfa[8], bfb[8];
     b_issue(0, bfa);
     for (int s = -TBK; s < T; ++s) {
       const int blk = s >= 0 ? s / TBK : -1;            // block the recurrence is in (-1: warm-up while block 0 is projected)
       const int sl = s - blk * TBK;                     // step inside the block, 0..TBK-1
       const int nb = blk + 1;                           // block being projected
       if (nb < nblk && a.dbg_role != 1) {
-        // A fragments are prefetched one unit ahead inside a block; the first unit of a block reads them after
-        // the barrier that published the block's LDS image.
         if (BT == 1) {                                   // one unit per step: the fragment buffers rotate through registers
-          if (sl == 0) a_issue(nb, 0, afa);
-          b_issue(sl + 1, bfb);
-          if (sl + 1 < 16) a_issue(nb, sl + 1, afb);
-          proj_unit(nb, sl, bfa, afa);
+          proj_unit(nb, sl, bfa, bfb);
 #pragma unroll
-          for (int g = 0; g < 8; ++g) { bfa[g] = bfb[g]; afa[g] = afb[g]; }
+          for (int g = 0; g < 8; ++g) bfa[g] = bfb[g];
         } else {
-          if (sl == 0) a_issue(nb, 0, afa);
 #pragma unroll
           for (int u = 0; u < BT; u += 2) {              // BT is even: units alternate between the two fragment buffers
-            const int u0 = sl * BT + u;
-            b_issue(u0 + 1, bfb); a_issue(nb, u0 + 1, afb);
-            proj_unit(nb, u0, bfa, afa);
-            b_issue(u0 + 2, bfa);
-            if (u0 + 2 < 16) a_issue(nb, u0 + 2, afa);
-            proj_unit(nb, u0 + 1, bfb, afb);
+            proj_unit(nb, sl * BT + u, bfa, bfb);
+            proj_unit(nb, sl * BT + u + 1, bfb, bfa);
           }
         }
       }
@@ -343,19 +339,20 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
     float z[BT];
 #pragma unroll
     for (int r = 0; r < BT; ++r) {
-      // plain v_fma_f32 here: packed f32 VALU shares the datapath the fp32 MFMAs of the projection waves run on
-      // (a v_pk_fma_f32 beside MFMAs costs ~22 cycles more than two v_fma_f32), plain FMAs issue in the MFMA's shadow
-      float s0 = xrow[r * RV_G], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      f2 a01 = f2{xrow[r * RV_G], 0.f}, a23 = f2{0.f, 0.f};
       const float4* hp = reinterpret_cast<const float4*>(hc + r * RV_U + 32 * kq);
 #pragma unroll
       for (int i4 = 0; i4 < 8; ++i4) {
         const float4 hv = hp[i4];
-#define RV_FMA4(H, I) s0 = __builtin_fmaf(H, u01[I].x, s0); s1 = __builtin_fmaf(H, u01[I].y, s1); \
-                      s2 = __builtin_fmaf(H, u23[I].x, s2); s3 = __builtin_fmaf(H, u23[I].y, s3);
-        RV_FMA4(hv.x, 4 * i4 + 0) RV_FMA4(hv.y, 4 * i4 + 1) RV_FMA4(hv.z, 4 * i4 + 2) RV_FMA4(hv.w, 4 * i4 + 3)
-#undef RV_FMA4
+        a01 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u01[4 * i4 + 0], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u23[4 * i4 + 0], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u01[4 * i4 + 1], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u23[4 * i4 + 1], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u01[4 * i4 + 2], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u23[4 * i4 + 2], a23);
+        a01 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u01[4 * i4 + 3], a01);
+        a23 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u23[4 * i4 + 3], a23);
       }
-      const f2 a01 = f2{s0, s1}, a23 = f2{s2, s3};
       float zz = a01.x + quad_perm<0x39>(a23.y);
       zz += quad_perm<0x4E>(a23.x);
       zz += quad_perm<0x93>(a01.y);
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
 template <int BT>
 void launch_proj(const RecArgs& a, hipStream_t s) {
   dim3 grid((a.B + BT - 1) / BT, 2);
-  const size_t shm = sizeof(float) * (2 * BT * RV_U + 2 * 16 * RV_G + 2 * 16 * 16 * 16);
+  const size_t shm = sizeof(float) * (2 * BT * RV_U + 2 * 16 * RV_G + RV_G + 2 * 16 * 260);
   hipLaunchKernelGGL((k_lstm_rec_proj<BT>), grid, dim3(768), shm, s, a);
 }
 
@@ -426,7 +423,7 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s) {
   }
 }
 void configure_rec_kernels() {
-  const int shm = (int)(sizeof(float) * (2 * 8 * RV_U + 2 * 16 * RV_G + 2 * 16 * 16 * 16));
+  const int shm = (int)(sizeof(float) * (2 * 8 * RV_U + 2 * 16 * RV_G + RV_G + 2 * 16 * 260));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<4>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
