@@ -35,8 +35,8 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
     return {
         "lstm_rec_raw_l0": B * T_r * (rec + 2 * 1 * 512 * 2),
         "lstm_rec_event_l0": B * T_e * (rec + 2 * 5 * 512 * 2),
-        "lstm_rec_raw_l1p": B * T_r * rec,
-        "lstm_rec_event_l1p": B * T_e * rec,
+        "lstm_rec_raw_l1p": B * T_r * (rec + 256 * 1024 * 2),      # recurrence + the fused input projection (MFMA waves)
+        "lstm_rec_event_l1p": B * T_e * (rec + 256 * 1024 * 2),
         "gemm_inproj_raw": B * T_r * 256 * 1024 * 2,     # both directions per launch
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
