@@ -855,13 +855,13 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention, beam search, decoder_depth 1, W <= 5 (register budget: 176 resident + 16*? work).
 struct PersistLds {
-  int xT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, total;
+  int attT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, total;
   __host__ __device__ PersistLds(int W) {
     int o = 0;
-    xT = o; o += RV_E * WB;            // cell input [attention | h], k-major beam-minor
+    attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127; rows 128..255 = hcT's h rows)
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     hS = o; o += W * RV_U;             // h of the beams (attention query)
-    cS = o; o += W * RV_U;
+    cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
     qp = o; o += W * RV_E;             // q' * log2(e)
     part = o; o += 8 * W * RV_E;       // partial sums ([8][W][256] / [16][W][128])
     hcT = o; o += (RV_U + RV_E) * WB;  // [h ; context] k-major beam-minor
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W);
-  float* xT = dsm + L.xT;  float* zb = dsm + L.zb;  float* hS = dsm + L.hS;  float* cS = dsm + L.cS;
+  float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* hS = dsm + L.hS;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
   __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
@@ -908,13 +908,18 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
   }
   // ---- decoder initial state: zeros; start tokens; log_probs = [0, -inf, ...]
-  for (int i = tid; i < RV_E * WB; i += NT) xT[i] = 0.f;
-  for (int i = tid; i < W * RV_U; i += NT) cS[i] = 0.f;
+  // The cell's matrix-vector product of a step is taken on the PREVIOUS step's beams, before they are re-ordered (it only
+  // needs their attention vector and h); the gate math then picks up the partial sums and the cell state of its parent
+  // beam.  Zero initial state: partial sums 0, parents = identity.
+  for (int i = tid; i < RV_U * WB; i += NT) attT[i] = 0.f;
+  for (int i = tid; i < (RV_U + RV_E) * WB; i += NT) hcT[i] = 0.f;
+  for (int i = tid; i < 2 * W * RV_U; i += NT) cS[i] = 0.f;
+  for (int i = tid; i < 4 * W * RV_G; i += NT) part[i] = 0.f;
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
   if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
   if (tid < WB) {
     s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
-    s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = 0;
+    s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = tid;
   }
   if (tid == 0) s_allfin = 0;
   for (int i = tid; i < V * RV_G; i += NT) zb[i] = Wtok[i] + bdec[i & (RV_G - 1)];   // W_dec[one_hot(v)] + b, resident
@@ -929,52 +934,20 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
     RV_STAMP(d, step, 0);
-    // ================= cell: z = [attention | h] . Wcat + W_dec[token] + b
-    //   thread = (4 gate columns c4, K quarter kg): 64 float4 weight loads in batches of 8 (64 KB in flight per CU)
-    {
-      const int c4 = tid & 127, kg = tid >> 7;
-      f2 acc[W][2];
-#pragma unroll
-      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-      const float* wc = Wcat + (size_t)(64 * kg) * RV_G + 4 * c4;
-      const float* xk = xT + (64 * kg) * WB;
-#pragma unroll 1
-      for (int k0 = 0; k0 < 64; k0 += 8) {
-        float4 wr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float xv[WB];
-          *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB]);
-          if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB + 4]);
-#pragma unroll
-          for (int w = 0; w < W; ++w) {
-            acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
-            acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
-          }
-        }
-      }
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
-      }
-    }
-    __syncthreads();
-    RV_STAMP(d, step, 1);
+    // ================= gates of this step: the cell product was taken at the end of the previous step on the parent beams
+    const int cb = step & 1;                             // cell-state buffer holding the previous step's states
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-quarter sums in fixed order, gate math, cell update
-      const int w = idx >> 7, u = idx & 127;
+      const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int col = g * RV_U + u;
-        z4[g] = (((part[(0 * W + w) * RV_G + col] + part[(1 * W + w) * RV_G + col]) + part[(2 * W + w) * RV_G + col]) +
-                 part[(3 * W + w) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
+        z4[g] = (((part[(0 * W + pb) * RV_G + col] + part[(1 * W + pb) * RV_G + col]) + part[(2 * W + pb) * RV_G + col]) +
+                 part[(3 * W + pb) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
       }
-      const float c2 = fmaf(rv_sigmoid(z4[1]), cS[idx], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
+      const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
-      cS[idx] = c2; hS[idx] = hh; hcT[u * WB + w] = hh;
+      cS[(cb ^ 1) * W * RV_U + idx] = c2; hS[idx] = hh; hcT[u * WB + w] = hh;
     }
     __syncthreads();
     RV_STAMP(d, step, 2);
@@ -1143,7 +1116,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       float s0 = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
-      att[i] = s0;
+      att[i] = s0; attT[col * WB + w] = s0;
     }
     __syncthreads();
     RV_STAMP(d, step, 8);
@@ -1200,25 +1173,41 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       if (lane == 0) s_allfin = __popcll(fmask) == W;
     }
-    __syncthreads();
-    RV_STAMP(d, step, 10);
-    // ================= next-step state, gathered by parent beam (read all, barrier, write)
-    {
-      float na[(W * RV_U + NT - 1) / NT], nh[(W * RV_U + NT - 1) / NT], nc[(W * RV_U + NT - 1) / NT];
+    // ================= next step's cell product on THIS step's beams: z~[w] = [attention_w | h_w] . Wcat (the beam step above
+    //   only decides which z~ each new beam inherits).  thread = (4 gate columns c4, K group kg); waves 1-7 start at once,
+    //   wave 0 joins after the beam step, so K group 0 (waves 0-1) is the short one: rows 0-39 | 40-111 | 112-183 | 184-255.
+    if (step + 1 < steps) {
+      const int c4 = tid & 127, kg = tid >> 7;
+      const int kb = kg == 0 ? 0 : 72 * kg - 32, ke = kg == 0 ? 40 : kb + 72;
+      f2 acc[W][2];
 #pragma unroll
-      for (int r = 0; r < (W * RV_U + NT - 1) / NT; ++r) {
-        const int i = tid + NT * r;
-        if (i < W * RV_U) { const int w = i >> 7, e = i & 127, p = s_parent[w]; na[r] = att[p * RV_U + e]; nh[r] = hS[p * RV_U + e]; nc[r] = cS[p * RV_U + e]; }
-      }
-      __syncthreads();
+      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+      const float* wc = Wcat + 4 * c4;
+#pragma unroll 1
+      for (int k0 = kb; k0 < ke; k0 += 8) {                // batches never straddle row 128 (40, 112 and 184 are multiples of 8)
+        float4 wr[8];
 #pragma unroll
-      for (int r = 0; r < (W * RV_U + NT - 1) / NT; ++r) {
-        const int i = tid + NT * r;
-        if (i < W * RV_U) { const int w = i >> 7, e = i & 127; xT[e * WB + w] = na[r]; xT[(RV_U + e) * WB + w] = nh[r]; cS[i] = nc[r]; }
+        for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* xk = k0 < RV_U ? attT + k0 * WB : hcT + (k0 - RV_U) * WB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float xv[WB];
+          *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&xk[i * WB]);
+          if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&xk[i * WB + 4]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
+          }
+        }
       }
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
     }
     __syncthreads();
-    RV_STAMP(d, step, 11);
+    RV_STAMP(d, step, 10);
     if (s_allfin) { done_steps = step + 1; break; }         // uniform: every thread reads the same LDS word
   }
   if (tid < W) { d.lengths[row0 + tid] = s_len[tid]; d.finished[row0 + tid] = (uint8_t)s_fin[tid]; }
