@@ -855,8 +855,8 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention, beam search, decoder_depth 1, W <= 5 (register budget: 176 resident + 16*? work).
 struct PersistLds {
-  int attT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, total;
-  __host__ __device__ PersistLds(int W) {
+  int attT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
+  __host__ __device__ PersistLds(int W, int D = 1) {
     int o = 0;
     attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127; rows 128..255 = hcT's h rows)
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
@@ -869,20 +869,29 @@ struct PersistLds {
     ml = o; o += 64 * WB;              // per-stream max [32][WB], per-stream sum [32][WB]
     mg = o; o += 2 * WB;               // merged max, 1/sum
     lg = o; o += WB * RV_MAX_VOCAB;
-    fold = o; o += 8 * 16 * 16 * 4;    // wave-private fold slab: 4 streams x 4 float4 x 16 lanes
+    fold = o; o += 8 * 16 * 16 * 4;    // wave-private fold slab: 4 streams x 4 float4 x 16 lanes; between the end of a step and
+                                       // the second cell's gate math it holds that cell's recurrent partial sums [3][W][512]
+    h0T = o; cS1 = o; b1s = o;
+    if (D > 1) {                       // StackedRNNCells, second cell (basecaller.py:85-91)
+      h0T = o; o += RV_U * WB;         // h of cell 0, k-major beam-minor (input of cell 1 and rows 128..255 of cell 0's product)
+      cS1 = o; o += 2 * W * RV_U;
+      b1s = o; o += RV_G;
+    }
     total = o;
   }
 };
 
-template <int W, int NIT>
+template <int W, int NIT, int D>
 __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ WmemT, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
-                                                      const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/) {
+                                                      const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/,
+                                                      const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1) {
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
-  const PersistLds L(W);
+  const PersistLds L(W, D);
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* hS = dsm + L.hS;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
+  float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = fold;   // D == 2 only
   __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
@@ -915,6 +924,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   for (int i = tid; i < (RV_U + RV_E) * WB; i += NT) hcT[i] = 0.f;
   for (int i = tid; i < 2 * W * RV_U; i += NT) cS[i] = 0.f;
   for (int i = tid; i < 4 * W * RV_G; i += NT) part[i] = 0.f;
+  if (D > 1) {
+    for (int i = tid; i < RV_U * WB; i += NT) h0T[i] = 0.f;
+    for (int i = tid; i < 2 * W * RV_U; i += NT) cS1[i] = 0.f;
+    for (int i = tid; i < 3 * W * RV_G; i += NT) partU[i] = 0.f;
+    b1s[tid] = bdec1[tid];
+  }
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
   if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
   if (tid < WB) {
@@ -947,9 +962,59 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
-      cS[(cb ^ 1) * W * RV_U + idx] = c2; hS[idx] = hh; hcT[u * WB + w] = hh;
+      cS[(cb ^ 1) * W * RV_U + idx] = c2; hS[idx] = hh;
+      if (D > 1) h0T[u * WB + w] = hh; else hcT[u * WB + w] = hh;
     }
     __syncthreads();
+    if (D > 1) {
+      // ---- second cell: z_1 = h_0(new) . W_1 + [h_1(prev) . U_1 of the parent beam, taken at the end of the previous step] + b_1
+      {
+        const int c4 = tid & 127, kg = tid >> 7;           // 32 rows of W_1 per K group
+        f2 acc[W][2];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+        const float* wc = Wcat1 + (size_t)(32 * kg) * RV_G + 4 * c4;
+        const float* xk = h0T + (32 * kg) * WB;
+#pragma unroll 1
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+          float4 wr[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float xv[WB];
+            *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB]);
+            if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&xk[(k0 + i) * WB + 4]);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
+              acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < W * RV_U; idx += NT) {
+        const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
+        float z4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = g * RV_U + u;
+          const float zin = ((part[(0 * W + w) * RV_G + col] + part[(1 * W + w) * RV_G + col]) + part[(2 * W + w) * RV_G + col]) +
+                            part[(3 * W + w) * RV_G + col];
+          const float zrec = (partU[(0 * W + pb) * RV_G + col] + partU[(1 * W + pb) * RV_G + col]) + partU[(2 * W + pb) * RV_G + col];
+          z4[g] = (zin + zrec) + b1s[col];
+        }
+        const float c2 = fmaf(rv_sigmoid(z4[1]), cS1[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
+        const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
+        cS1[(cb ^ 1) * W * RV_U + idx] = c2; hcT[u * WB + w] = hh;
+      }
+      __syncthreads();
+    }
     RV_STAMP(d, step, 2);
     // ================= q' = W_mem . h (times log2 e)
     {
@@ -1178,7 +1243,9 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     //   wave 0 joins after the beam step, so K group 0 (waves 0-1) is the short one: rows 0-39 | 40-111 | 112-183 | 184-255.
     if (step + 1 < steps) {
       const int c4 = tid & 127, kg = tid >> 7;
-      const int kb = kg == 0 ? 0 : 72 * kg - 32, ke = kg == 0 ? 40 : kb + 72;
+      // one cell: rows 0-39 | 40-111 | 112-183 | 184-255;  two cells: 64 rows each here, and K groups 1-3 also take the
+      // second cell's recurrent product below (48 / 40 / 40 rows)
+      const int kb = D > 1 ? 64 * kg : (kg == 0 ? 0 : 72 * kg - 32), ke = D > 1 ? kb + 64 : (kg == 0 ? 40 : kb + 72);
       f2 acc[W][2];
 #pragma unroll
       for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
@@ -1189,7 +1256,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
         for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
         __builtin_amdgcn_sched_barrier(0);
-        const float* xk = k0 < RV_U ? attT + k0 * WB : hcT + (k0 - RV_U) * WB;
+        const float* xk = k0 < RV_U ? attT + k0 * WB : (D > 1 ? h0T : hcT) + (k0 - RV_U) * WB;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           float xv[WB];
@@ -1205,6 +1272,33 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int w = 0; w < W; ++w)
         *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+      if (D > 1 && kg > 0) {            // h_1 . U_1 of this step's beams (U_1 = rows 128..255 of Wcat1; h_1 = hcT's h rows)
+        const int rb = kg == 1 ? 0 : 8 + 40 * (kg - 1), re = kg == 1 ? 48 : rb + 40;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+        const float* wu = Wcat1 + (size_t)RV_U * RV_G + 4 * c4;
+#pragma unroll 1
+        for (int k0 = rb; k0 < re; k0 += 8) {
+          float4 wr[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wu + (size_t)(k0 + i) * RV_G);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float xv[WB];
+            *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&hcT[(k0 + i) * WB]);
+            if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&hcT[(k0 + i) * WB + 4]);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
+              acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          *reinterpret_cast<float4*>(&partU[((kg - 1) * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+      }
     }
     __syncthreads();
     RV_STAMP(d, step, 10);
@@ -1309,23 +1403,31 @@ __global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict
 
 }  // namespace
 
+template <int W, int D>
+static void launch_persist_wd(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+                              const float* Wcat1, const float* bdec1, hipStream_t s) {
+  const size_t shm = sizeof(float) * PersistLds(W, D).total;
+  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
+  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
+  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
+}
 template <int W>
-static void launch_persist_w(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec, hipStream_t s) {
-  const size_t shm = sizeof(float) * PersistLds(W).total;
-  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
-  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
-  else hipLaunchKernelGGL((k_dec_persist<W, 11>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec);
+static void launch_persist_w(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+                             const float* Wcat1, const float* bdec1, hipStream_t s) {
+  if (d.depth > 1) launch_persist_wd<W, 2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
+  else launch_persist_wd<W, 1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  return !d.greedy && d.attention == 0 && d.depth == 1 && d.W <= 5 && d.Tm <= 352 && !d.step_logits && !d.step_align;
+  return !d.greedy && d.attention == 0 && d.depth <= 2 && d.W <= 5 && d.Tm <= 352 && !d.step_logits && !d.step_align;
 }
-void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec, hipStream_t s) {
+void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+                        const float* Wcat1, const float* bdec1, hipStream_t s) {
   switch (d.W) {
-    case 1: launch_persist_w<1>(d, WmemT, Wcat, Wtok, bdec, s); break;
-    case 2: launch_persist_w<2>(d, WmemT, Wcat, Wtok, bdec, s); break;
-    case 3: launch_persist_w<3>(d, WmemT, Wcat, Wtok, bdec, s); break;
-    case 4: launch_persist_w<4>(d, WmemT, Wcat, Wtok, bdec, s); break;
-    default: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, s); break;
+    case 1: launch_persist_w<1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 2: launch_persist_w<2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 3: launch_persist_w<3>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 4: launch_persist_w<4>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    default: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
   }
   hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
 }
@@ -1397,9 +1499,12 @@ static void configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), sizeof(float) * AttLds(W, 0, true, 256).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), sizeof(float) * AttLds(W, 0, true, 512).total);
   if constexpr (W <= 5) {
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2>), sizeof(float) * PersistLds(W).total);
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8>), sizeof(float) * PersistLds(W).total);
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11>), sizeof(float) * PersistLds(W).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1>), sizeof(float) * PersistLds(W, 1).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1>), sizeof(float) * PersistLds(W, 1).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1>), sizeof(float) * PersistLds(W, 1).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);
+    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 2>), sizeof(float) * PersistLds(W, 2).total);
   }
 }
 void configure_decode_kernels() {

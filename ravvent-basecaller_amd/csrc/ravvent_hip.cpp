@@ -439,7 +439,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if (h->lpersist) {
     part[0] = d; part[0].part = 0; parts.n = 1;
     Scope sc(h, "dec_persist", nullptr, true);
-    launch_dec_persist(d, h->d_WmemT, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b, s);
+    launch_dec_persist(d, h->d_WmemT, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b,
+                       d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, s);
   } else if (h->opt_graph && h->opt_profile != 2) {
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
     auto it = h->graphs.find(key);
