@@ -1205,7 +1205,9 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const bool cand = lane < W * V;
       const size_t o = ((size_t)step * d.B + b) * W;
       float val = -INFINITY;
-      if (cand) {
+      if (d.greedy) {                  // GreedyEmbeddingSampler: argmax of the raw logits (W == 1)
+        if (cand) { val = lg[v]; d.step_logits[((size_t)step * d.B + b) * V + v] = val; }
+      } else if (cand) {
         float m = lg[w * RV_MAX_VOCAB];
         for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
         float ssum = 0.f;
@@ -1232,11 +1234,26 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         nl = s_len[my_par] + (pf ? 0 : 1);
       }
       const unsigned long long fmask = __ballot(lane < W && nf);
+      if (d.greedy) {
+        // BasicDecoder without impute_finished: a finished row keeps sampling and the loop runs until EVERY row of the
+        // slab has finished, so a chunk may only stop once all chunks have reported their first finished step
+        // (nfin[0] = how many have, nfin[1] = the latest of those steps + 1) and it has itself recorded that many steps.
+        if (lane == 0) {
+          const bool pf = s_fin[0] != 0;
+          d.step_ids[(size_t)step * d.B + b] = my_word;
+          s_tok[0] = my_word; s_fin[0] = nf; s_parent[0] = 0;
+          if (nf && !pf) { s_len[0] = step + 1; atomicMax(&d.nfin[1], step + 1); __threadfence(); atomicAdd(&d.nfin[0], 1); }
+          const int cnt = __hip_atomic_load(&d.nfin[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int sg = __hip_atomic_load(&d.nfin[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_allfin = nf && cnt >= d.B && step + 1 >= sg;
+        }
+      } else {
       if (lane < W) {      // all reads of the old bookkeeping happened above (same wave, program order)
         d.step_ids[o + lane] = my_word; d.parent_ids[o + lane] = my_par; d.step_scores[o + lane] = my_val;
         s_tok[lane] = my_word; s_fin[lane] = nf; s_lprob[lane] = my_val; s_len[lane] = nl; s_parent[lane] = my_par;
       }
       if (lane == 0) s_allfin = __popcll(fmask) == W;
+      }
     }
     // ================= next step's cell product on THIS step's beams: z~[w] = [attention_w | h_w] . Wcat (the beam step above
     //   only decides which z~ each new beam inherits).  thread = (4 gate columns c4, K group kg); waves 1-7 start at once,
@@ -1305,7 +1322,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     if (s_allfin) { done_steps = step + 1; break; }         // uniform: every thread reads the same LDS word
   }
   if (tid < W) { d.lengths[row0 + tid] = s_len[tid]; d.finished[row0 + tid] = (uint8_t)s_fin[tid]; }
-  if (tid == 0) d.chunk_steps[b] = done_steps;
+  if (tid == 0) d.chunk_steps[b] = d.greedy ? (s_fin[0] ? s_len[0] : steps) : done_steps;   // greedy: the row's first finished step + 1
 }
 
 // One 64-thread workgroup per chunk: the chunk's [S,W] ids/parents are staged in LDS so the
@@ -1418,7 +1435,7 @@ static void launch_persist_w(const DecState& d, const float* WmemT, const float*
   else launch_persist_wd<W, 1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  return !d.greedy && d.attention == 0 && d.depth <= 2 && d.W <= 5 && d.Tm <= 352 && !d.step_logits && !d.step_align;
+  return d.attention == 0 && d.depth <= 2 && d.W <= 5 && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
 }
 void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
                         const float* Wcat1, const float* bdec1, hipStream_t s) {

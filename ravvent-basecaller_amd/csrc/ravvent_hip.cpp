@@ -438,6 +438,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   };
   if (h->lpersist) {
     part[0] = d; part[0].part = 0; parts.n = 1;
+    if (greedy) HIPCHK(h, hipMemsetAsync(d.nfin, 0, 2 * sizeof(int), s));   // chunks-finished count and latest first-finish step
     Scope sc(h, "dec_persist", nullptr, true);
     launch_dec_persist(d, h->d_WmemT, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b,
                        d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, s);

@@ -49,6 +49,36 @@ def test_greedy_tensors_and_strings(rv, oracle, mode, attention, enc_depth):
     bc.close()
 
 
+@pytest.mark.parametrize("B,Tr,Te,L,dec_depth,end_bias", [(9, 120, 20, 30, 1, 0.0), (300, 50, 10, 20, 1, 1.2), (7, 300, 30, 24, 2, 0.8),
+                                                          (1, 33, 0, 12, 1, 2.0)])
+def test_persistent_greedy_matches_per_step_and_oracle(rv, oracle, B, Tr, Te, L, dec_depth, end_bias):
+    """greedy_search_prediction on the one-launch decode: rows keep sampling after their own end token and the slab stops
+    at the step where the LAST row finishes (chunks report their first finished step through two global counters)."""
+    mode = "joint" if Te else "raw"
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, decoder_depth=dec_depth, max_batch=B)
+    flat = rv.weights.init_weights(bc.cfg, seed=17)
+    flat["b_fc"][bc.cfg.end_token] = end_bias            # rows finish at different steps (or never)
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, max(Te, 1), seed=B)
+    x = (raw, ev) if mode == "joint" else raw
+    out = {}
+    bc.set_option("profile", 1)
+    for persist in (1, 0):
+        bc.set_option("persistent_decode", persist)
+        bc.reset_profile()
+        tok, lg = bc.greedy_search_prediction(x, L)
+        assert ("dec_persist" in bc.profile()) == bool(persist)
+        out[persist] = (tok.numpy().copy(), lg.numpy().copy())
+    assert out[1][0].shape == out[0][0].shape and (out[1][0] == out[0][0]).all()
+    assert np.abs(out[1][1] - out[0][1]).max() < TOL
+    nb = min(B, 12)
+    ot, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw[:nb], ev[:nb] if mode == "joint" else None, L)
+    S = min(ot.shape[1], out[1][0].shape[1])              # the oracle's sub-slab may stop earlier than the full slab
+    assert (out[1][0][:nb, :S] == ot[:, :S]).all() and np.abs(out[1][1][:nb, :S] - olg[:, :S]).max() < TOL
+    bc.close()
+
+
 @pytest.mark.parametrize("W", [1, 3, 5, 8])
 def test_beam_search_matches_oracle(rv, oracle, W):
     bc, w = _mk(rv)
