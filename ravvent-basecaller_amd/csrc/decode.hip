@@ -855,12 +855,11 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention, beam search, decoder_depth 1, W <= 5 (register budget: 176 resident + 16*? work).
 struct PersistLds {
-  int attT, zb, hS, cS, qp, part, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
+  int attT, zb, cS, qp, part, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
   __host__ __device__ PersistLds(int W, int D = 1) {
     int o = 0;
     attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127; rows 128..255 = hcT's h rows)
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
-    hS = o; o += W * RV_U;             // h of the beams (attention query)
     cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
     qp = o; o += W * RV_E;             // q' * log2(e)
     part = o; o += 8 * W * RV_E;       // partial sums ([8][W][256] / [16][W][128])
@@ -888,7 +887,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D);
-  float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* hS = dsm + L.hS;  float* cS = dsm + L.cS;
+  float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
   float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = fold;   // D == 2 only
@@ -962,7 +961,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
-      cS[(cb ^ 1) * W * RV_U + idx] = c2; hS[idx] = hh;
+      cS[(cb ^ 1) * W * RV_U + idx] = c2;
       if (D > 1) h0T[u * WB + w] = hh; else hcT[u * WB + w] = hh;
     }
     __syncthreads();
