@@ -374,6 +374,29 @@ def test_random_shapes_against_c_port(rv):
         bc.close()
 
 
+@pytest.mark.parametrize("W", [5, 8, 1])
+def test_maximum_shapes_against_c_port(rv, W):
+    """The library's limits at once: T_raw + T_event = 352 (all 11 resident row groups of the persistent decode in use),
+    max_output_len 64, beam 5 (persistent decode) / 8 (per-step kernels) / 1, a slab larger than the CU count."""
+    from oracle import cpu_port
+    B, T_r, T_e, L = 300, 307, 45, 64
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_r, max_event_len=T_e,
+                       max_output_len=L)
+    flat = rv.weights.init_weights(bc.cfg, seed=41)
+    flat["b_fc"][bc.cfg.end_token] = 0.4 if W != 8 else 0.0
+    bc.set_weights_flat(flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=W)
+    tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+    ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
+    assert tok.shape == ctok.shape
+    same = (tok.numpy() == ctok).all(axis=1)
+    assert same.mean() >= 0.98, same.mean()
+    assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL
+    with pytest.raises(rv._capi.RavventHipError):
+        bc.beam_search_prediction((raw, ev), W, L + 1)
+    bc.close()
+
+
 @pytest.mark.parametrize("dec_depth,enc_depth", [(2, 3), (3, 2)])
 def test_stacked_decoder_cells(rv, oracle, dec_depth, enc_depth):
     """decoder_depth > 1 (StackedRNNCells, basecaller.py:85-91): the reference's enc3/dec2 model family."""
