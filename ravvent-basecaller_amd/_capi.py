@@ -60,7 +60,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RAVVENT_HIP_LIB") or LIB_PATH     # RAVVENT_HIP_LIB: an alternative build of the same ABI (A/B timing)
     if not os.path.exists(p):
         raise RavventHipError(f"{p} not found: build the HIP library first (there is no CPU fallback)")
     try:   # torch bundles its own libamdhip64.so.7; load it first so both share one HIP runtime
