@@ -948,6 +948,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
     RV_STAMP(d, step, 0);
+    float4 pw[8];                      // first W_mem batch of the q' phase: requested before the (last) gate math, which it does not depend on
+    auto q_prefetch = [&]() {
+      const float* wp = WmemT + (size_t)(16 * (tid >> 6)) * RV_E + 4 * (tid & 63);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
+    };
+    if (D == 1) q_prefetch();
     // ================= gates of this step: the cell product was taken at the end of the previous step on the parent beams
     const int cb = step & 1;                             // cell-state buffer holding the previous step's states
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-quarter sums in fixed order, gate math, cell update
@@ -996,6 +1003,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         for (int w = 0; w < W; ++w)
           *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
       }
+      q_prefetch();
       __syncthreads();
       for (int idx = tid; idx < W * RV_U; idx += NT) {
         const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
@@ -1021,13 +1029,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       f2 acc[W][2];
 #pragma unroll
       for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-#pragma unroll 1
-      for (int j0 = 0; j0 < 16; j0 += 8) {
-        float4 wm[8];
-        const float* wp = WmemT + (size_t)(16 * jg + j0) * RV_E + 4 * c4;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
-        __builtin_amdgcn_sched_barrier(0);
+      auto fma8 = [&](const float4* wm, int j0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           float hv[WB];
@@ -1039,6 +1041,16 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
           }
         }
+      };
+      fma8(pw, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        float4 wm[8];
+        const float* wp = WmemT + (size_t)(16 * jg + 8) * RV_E + 4 * c4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
+        __builtin_amdgcn_sched_barrier(0);
+        fma8(wm, 8);
       }
 #pragma unroll
       for (int w = 0; w < W; ++w)
@@ -1132,6 +1144,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         asm volatile("" ::: "memory");
       }
     }
+    float4 pa[8];                      // first W_att batch of the attention layer: in flight across the barrier and the cross-wave context sum
+    {
+      const float* wa = d.W_att + (size_t)(24 * (tid >> 5)) * RV_U + 4 * (tid & 31);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pa[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+    }
     __syncthreads();
     RV_STAMP(d, step, 6);
     for (int i = tid; i < W * RV_E; i += NT) {              // fixed-order reduction over the 8 waves
@@ -1150,13 +1168,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       f2 acc[W][2];
 #pragma unroll
       for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-#pragma unroll 1
-      for (int k0 = 0; k0 < 24; k0 += 8) {
-        float4 wa4[8];
-        const float* wa = d.W_att + (size_t)(24 * kg + k0) * RV_U + 4 * d4;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wa4[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
-        __builtin_amdgcn_sched_barrier(0);
+      auto fma8 = [&](const float4* wa4, int k0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           float hv[WB];
@@ -1168,6 +1180,17 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wa4[u].z, wa4[u].w}, acc[w][1]);
           }
         }
+      };
+      fma8(pa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+      for (int k0 = 8; k0 < 24; k0 += 8) {
+        float4 wa4[8];
+        const float* wa = d.W_att + (size_t)(24 * kg + k0) * RV_U + 4 * d4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wa4[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+        __builtin_amdgcn_sched_barrier(0);
+        fma8(wa4, k0);
       }
 #pragma unroll
       for (int w = 0; w < W; ++w)
