@@ -1207,16 +1207,18 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     __syncthreads();
     RV_STAMP(d, step, 8);
-    // ================= logits = attention . W_fc + b_fc
+    // ================= logits = attention . W_fc + b_fc: 8 lanes per output, all W*V <= 35 outputs in one pass
     {
-      const int o = tid >> 4;
-      for (int ob = o; ob < W * V; ob += NT / 16) {
-        const int w = ob / V, v = ob % V;
+      const int o8 = tid >> 3, s8 = tid & 7;
+      if (o8 < W * V) {                                     // whole 8-lane groups take the branch together
+        const int w = o8 / V, v = o8 % V;
         float p = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p = fmaf(att[w * RV_U + 8 * sub + i], s_wfc[(8 * sub + i) * V + v], p);
-        p = row16_sum(p) + s_wfc[RV_U * V + v];
-        if (sub == 0) lg[w * RV_MAX_VOCAB + v] = p;
+        for (int i = 0; i < 16; ++i) p = fmaf(att[w * RV_U + 8 * i + s8], s_wfc[(8 * i + s8) * V + v], p);
+        p += dpp<0xB1>(p);    // quad_perm [1,0,3,2]
+        p += dpp<0x4E>(p);    // quad_perm [2,3,0,1]
+        p += dpp<0x141>(p);   // row_half_mirror: the other quad of this 8-lane group
+        if (s8 == 0) lg[w * RV_MAX_VOCAB + v] = p + s_wfc[RV_U * V + v];
       }
     }
     __syncthreads();
