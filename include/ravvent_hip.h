@@ -113,7 +113,7 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       0 = two-pass keys-then-values dataflow of the reference),
  *          "concurrent_encoders" (0/1, default 1: in joint mode the event encoder runs on a side stream under the
  *                       raw encoder's input-projection GEMM; results are identical),
- *          "persistent_decode" (0/1, default 1: Luong beam search with beam <= 5 and greedy search, decoder_depth <= 2, no
+ *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.
  *                       The step_ids / parent_ids / step_scores taps of a chunk then end at its own last

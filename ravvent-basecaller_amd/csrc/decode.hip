@@ -853,7 +853,7 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // records that step; k_dec_finalize extends earlier finishers exactly as the shared loop would
 // (end token, unchanged score -- SURVEY.md A.5).  No hipGraph, no per-step launches, no HBM stream:
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
-// Luong attention, beam search, decoder_depth 1, W <= 5 (register budget: 176 resident + 16*? work).
+// Luong attention; beam search with W <= 8 (W <= 5 with two stacked cells: LDS) and greedy search.
 struct PersistLds {
   int attT, zb, cS, qp, part, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
   __host__ __device__ PersistLds(int W, int D = 1) {
@@ -1455,11 +1455,13 @@ static void launch_persist_wd(const DecState& d, const float* WmemT, const float
 template <int W>
 static void launch_persist_w(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
                              const float* Wcat1, const float* bdec1, hipStream_t s) {
-  if (d.depth > 1) launch_persist_wd<W, 2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
-  else launch_persist_wd<W, 1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
+  if constexpr (W <= 5) {
+    if (d.depth > 1) { launch_persist_wd<W, 2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); return; }
+  }
+  launch_persist_wd<W, 1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  return d.attention == 0 && d.depth <= 2 && d.W <= 5 && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
+  return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
 }
 void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
                         const float* Wcat1, const float* bdec1, hipStream_t s) {
@@ -1468,7 +1470,10 @@ void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat
     case 2: launch_persist_w<2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
     case 3: launch_persist_w<3>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
     case 4: launch_persist_w<4>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    default: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 5: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 6: launch_persist_w<6>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 7: launch_persist_w<7>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    default: launch_persist_w<8>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
   }
   hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
 }
@@ -1539,10 +1544,10 @@ static void configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_attend<W, 11, 44>), sizeof(float) * AttLds(W, 352, false).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 256>), sizeof(float) * AttLds(W, 0, true, 256).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend_flash<W, 512>), sizeof(float) * AttLds(W, 0, true, 512).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1>), sizeof(float) * PersistLds(W, 1).total);
   if constexpr (W <= 5) {
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1>), sizeof(float) * PersistLds(W, 1).total);
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1>), sizeof(float) * PersistLds(W, 1).total);
-    opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1>), sizeof(float) * PersistLds(W, 1).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 2>), sizeof(float) * PersistLds(W, 2).total);

@@ -348,7 +348,10 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   //      kernel and for the "keys" debug tap only.
   const int W_eff = greedy ? 1 : W;
   h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && W_eff <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
-  h->lkeys = (!h->lflash || h->opt_taps) ? 1 : 0;
+  // the persistent decode (decided below, once the decode state is set up) needs neither keys nor the per-step kernels
+  const bool persist_ok = h->opt_persist && h->opt_flash && c.attention == RV_ATT_LUONG && !h->opt_taps && c.dec_depth <= 2 &&
+                          W_eff <= (c.dec_depth > 1 ? 5 : 8) && Tm <= 352;
+  h->lkeys = ((!h->lflash && !persist_ok) || h->opt_taps) ? 1 : 0;
   if (h->lkeys) {
     GemmArgs g{};
     g.A = h->enc_out; g.lda = RV_E; g.Bm = h->W_mem; g.ldb = RV_U; g.C = h->keys; g.ldc = RV_U;
@@ -394,7 +397,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   // keep sampling after their end token, so greedy decodes as one piece).
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
   d.chunk_steps = nullptr;
-  h->lpersist = (h->opt_persist && h->lflash && !h->opt_taps && dec_persist_supported(d)) ? 1 : 0;
+  h->lpersist = (persist_ok && dec_persist_supported(d)) ? 1 : 0;
+  if (persist_ok && !h->lpersist) return fail(h, RV_ESTATE, "internal: persistent decode predicate mismatch");
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
   h->lsplit = nsplit;
   if (!h->lpersist) {

@@ -194,7 +194,8 @@ def test_flash_and_two_pass_attend_agree(rv, oracle):
 
 @pytest.mark.parametrize("B,Tr,Te,W,L,dec_depth", [(16, 90, 20, 5, 20, 1), (9, 300, 30, 5, 32, 1), (5, 40, 8, 3, 12, 1),
                                                    (7, 200, 0, 1, 16, 1), (6, 0, 45, 4, 14, 1), (3, 320, 32, 2, 10, 1),
-                                                   (11, 120, 25, 5, 24, 2), (4, 300, 30, 3, 12, 2), (6, 60, 0, 1, 10, 2)])
+                                                   (11, 120, 25, 5, 24, 2), (4, 300, 30, 3, 12, 2), (6, 60, 0, 1, 10, 2),
+                                                   (10, 300, 30, 8, 20, 1), (5, 100, 12, 6, 16, 1), (3, 30, 45, 7, 12, 1)])
 def test_persistent_decode_matches_per_step_graph(rv, oracle, B, Tr, Te, W, L, dec_depth):
     """One-launch register-resident decode == per-step kernels == oracle (tokens exact, scores within TOL); one and two
     stacked decoder cells (the reference's decd1 / decd2 model families)."""
