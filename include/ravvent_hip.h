@@ -113,6 +113,9 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       0 = two-pass keys-then-values dataflow of the reference),
  *          "concurrent_encoders" (0/1, default 1: in joint mode the event encoder runs on a side stream under the
  *                       raw encoder's input-projection GEMM; results are identical),
+ *          "fused_projection" (0/1, default 1: encoder layers >= 1 compute their input projection inside the
+ *                       recurrence kernel, on MFMA waves of the same workgroup; 0 = separate GEMM launch + pre-projected
+ *                       tensor; results agree to fp32 rounding),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

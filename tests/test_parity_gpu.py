@@ -246,6 +246,22 @@ def test_fused_projection_matches_gemm_path_and_oracle(rv, oracle, mode, B, Tr, 
     bc.close()
 
 
+def test_every_documented_option_is_accepted(rv):
+    """rv_set_option: every key the header documents exists, an unknown key is an error (include/ravvent_hip.h)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "ravvent_hip.h")).read()
+    doc = hdr[hdr.index("/* Options:"):hdr.index("int rv_set_option")]
+    keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
+    assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
+            "fused_projection", "persistent_decode", "profile"} <= keys
+    bc, _ = _mk(rv)
+    for k in sorted(keys):
+        bc.set_option(k, 1 if k != "attend_threads" else 256)
+    with pytest.raises(rv._capi.RavventHipError):
+        bc.set_option("no_such_option", 1)
+    bc.close()
+
+
 def test_device_and_host_inputs_agree(rv):
     import torch
     bc, _ = _mk(rv)
