@@ -134,3 +134,48 @@ class PerformanceEvaluator:
             "total": t_data_loading + t_predicting + t_merge, "total_processing": t_predicting + t_merge,
             "nuc_preds": nuc_preds, "merged_seq": merged_seq,
         }
+
+    def run_many(self, reads, chunk_size: int = 1024, beam_width: int = 5, max_output_len: int | None = None,
+                 merge_threads: int = 4):
+        """Many reads through shared slabs (short reads leave a GPU's slab half empty; the chunks of all
+        reads are queued into full slabs, decoded, and stitched back per read).
+
+        reads: list of (raw_snippets [n_i,T_r,1], event_snippets [n_i,T_e,5], nuc_tk_snippets [n_i,L_i]) as
+        `load_data_from_single_signal_label` returns them (one tuple per read).  Returns one dict per read with
+        `merged_seq`, `chunks_num`, plus the shared timers under key "timing" of the first entry.  The reference has no
+        counterpart (it evaluates one read at a time); per-read results equal `run_slabs` of that read alone when
+        `max_output_len` is given or all reads share one target length."""
+        from concurrent.futures import ThreadPoolExecutor
+        start = timer()
+        n = [int(r[0].shape[0]) for r in reads]
+        off = np.concatenate([[0], np.cumsum(n)])
+        L = int(max_output_len) if max_output_len is not None else max(int(r[2].shape[1]) for r in reads)
+        raw = np.concatenate([r[0] for r in reads], axis=0) if self.basecaller.input_data_type != "event" else None
+        ev = np.concatenate([r[1] for r in reads], axis=0) if self.basecaller.input_data_type != "raw" else None
+        total = int(off[-1])
+        t_data_loading = timer() - start
+        bases = np.zeros((total, max(L - 1, 1)), np.uint8)
+        probs = np.zeros((total, max(L - 1, 1)), np.float32)
+        lens = np.zeros(total, np.int32)
+        t_predicting = 0.0
+        for b0 in range(0, total, chunk_size):
+            b1 = min(b0 + chunk_size, total)
+            start = timer()
+            x = (raw[b0:b1], ev[b0:b1]) if self.basecaller.input_data_type == "joint" else (raw[b0:b1] if raw is not None else ev[b0:b1])
+            bs, pr, ln = self.basecaller.beam_search_call_arrays(x, beam_width=beam_width, max_output_len=L)
+            bases[b0:b1, :bs.shape[1]] = bs; probs[b0:b1, :pr.shape[1]] = pr; lens[b0:b1] = ln
+            t_predicting += timer() - start
+        start = timer()
+
+        def merge_one(i):
+            if n[i] == 0:
+                return ""
+            return self.merger.merge_arrays(bases[off[i]:off[i + 1]], probs[off[i]:off[i + 1]], lens[off[i]:off[i + 1]])[0]
+        with ThreadPoolExecutor(max_workers=max(1, merge_threads)) as pool:      # reads are independent; ctypes drops the GIL
+            merged = list(pool.map(merge_one, range(len(reads))))
+        t_merge = timer() - start
+        out = [{"merged_seq": m, "chunks_num": n[i]} for i, m in enumerate(merged)]
+        if out:
+            out[0]["timing"] = {"t_data_loading": t_data_loading, "t_predicting": t_predicting, "t_postprocessing": 0.0,
+                                "t_merge": t_merge, "total_processing": t_predicting + t_merge, "chunks_num": total}
+        return out

@@ -364,6 +364,24 @@ def test_read_level_pipeline(rv):
     bc.close()
 
 
+def test_many_reads_share_slabs(rv):
+    """evaluator.run_many: chunks of several reads queued into common slabs == every read evaluated alone."""
+    bc, _ = _mk(rv, max_batch=64)
+    ev_ = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True)
+    reads = []
+    for i, n in enumerate((37, 5, 0, 90, 64)):
+        raw, ev, nuc = rv.synthetic.make_slab(max(n, 1), 60, 10, seed=20 + i, L=12)
+        reads.append((raw[:n], ev[:n], nuc[:n]))
+    out = ev_.run_many(reads, chunk_size=64)
+    assert len(out) == 5 and out[0]["timing"]["chunks_num"] == 196 and out[2]["merged_seq"] == ""
+    for i, r in enumerate(reads):
+        if r[0].shape[0] == 0:
+            continue
+        alone = ev_.run_slabs(*r, chunk_size=64)
+        assert out[i]["merged_seq"] == alone["merged_seq"] and out[i]["chunks_num"] == alone["chunks_num"]
+    bc.close()
+
+
 def test_random_shapes_against_c_port(rv):
     """Shape fuzz: ragged batch / time / beam / length combinations in all three input modes."""
     from oracle import cpu_port
