@@ -40,6 +40,7 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
         "gemm_inproj_raw": B * T_r * 256 * 1024 * 2,     # both directions per launch
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
+        "gemm_memory": B * Tm * 256 * 256 * 2,               # [keys | attention-layer image of the values] for the persistent decode
         "decode_graph": B * W * S * (369408 + 768 * Tm),
         "dec_persist": B * W * S * (369408 + 768 * Tm),      # the whole decode loop is one launch
         "dec_cell": B * W * 2 * 256 * 512,

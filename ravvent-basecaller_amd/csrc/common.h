@@ -111,10 +111,12 @@ void launch_dec_cell(const DecState& d, int layer, const float* WcatT /*[512,256
                      const float* bias /*[512]*/, int step, hipStream_t s);
 // flash: single-pass Luong attend over `values` only (WmemT = W_mem^T [128,256]); else the two-pass kernel
 void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int step, hipStream_t s);
-// Persistent decode (Luong beam search, W <= 5, one or two stacked decoder cells, no taps): the whole loop in one launch,
-// the chunk's attention memory resident in registers; also writes S_dev[0..1].  Wcat1 / bdec1: second cell ([W_1;U_1], b_1) or null.
+// Persistent decode (Luong beam search with W <= 8, W <= 5 with two stacked cells; greedy search; no taps): the whole loop in
+// one launch, the chunk's attention memory resident in registers; also writes S_dev[0..1].  d.values must point at the
+// PROJECTED memory [B,Tm,256] = enc_output . [W_mem | A_c] (keys | attention-layer image of the values).
+// Wcat1 / bdec1: second cell ([W_1;U_1], b_1) or null.
 bool dec_persist_supported(const DecState& d);
-void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
+void launch_dec_persist(const DecState& d, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
                         const float* bdec /*[512]*/, const float* Wcat1, const float* bdec1, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
 struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; };

@@ -855,21 +855,23 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention; beam search with W <= 8 (W <= 5 with two stacked cells: LDS) and greedy search.
 struct PersistLds {
-  int attT, zb, cS, qp, part, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
+  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
   __host__ __device__ PersistLds(int W, int D = 1) {
     int o = 0;
-    attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127; rows 128..255 = hcT's h rows)
+    attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127)
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
-    qp = o; o += W * RV_E;             // q' * log2(e)
-    part = o; o += 8 * W * RV_E;       // partial sums ([8][W][256] / [16][W][128])
-    hcT = o; o += (RV_U + RV_E) * WB;  // [h ; context] k-major beam-minor
+    qp = o; o += W * RV_U;             // h * log2(e): the score query
+    part = o; o += 4 * W * RV_G;       // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
+                                       // layer's h-part partial sums [16][W][128] (after the gates -> merge)
+    ctxp = o; o += 8 * W * RV_U;       // context partial sums of the 8 waves [8][W][128]
+    fold = o; o += 8 * 4 * 2 * 16 * 4; // wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
+                                       // second cell's recurrent partial sums [3][W][512] between the end of a step and its gates
+    hcT = o; o += RV_U * WB;           // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
     att = o; o += W * RV_U;
     ml = o; o += 64 * WB;              // per-stream max [32][WB], per-stream sum [32][WB]
     mg = o; o += 2 * WB;               // merged max, 1/sum
     lg = o; o += WB * RV_MAX_VOCAB;
-    fold = o; o += 8 * 16 * 16 * 4;    // wave-private fold slab: 4 streams x 4 float4 x 16 lanes; between the end of a step and
-                                       // the second cell's gate math it holds that cell's recurrent partial sums [3][W][512]
     h0T = o; cS1 = o; b1s = o;
     if (D > 1) {                       // StackedRNNCells, second cell (basecaller.py:85-91)
       h0T = o; o += RV_U * WB;         // h of cell 0, k-major beam-minor (input of cell 1 and rows 128..255 of cell 0's product)
@@ -881,16 +883,16 @@ struct PersistLds {
 };
 
 template <int W, int NIT, int D>
-__global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ WmemT, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
+__global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
                                                       const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/,
                                                       const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1) {
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D);
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
-  float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
+  float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* ctxp = dsm + L.ctxp;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
-  float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = fold;   // D == 2 only
+  float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (spans ctxp + fold)
   __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   // needs their attention vector and h); the gate math then picks up the partial sums and the cell state of its parent
   // beam.  Zero initial state: partial sums 0, parents = identity.
   for (int i = tid; i < RV_U * WB; i += NT) attT[i] = 0.f;
-  for (int i = tid; i < (RV_U + RV_E) * WB; i += NT) hcT[i] = 0.f;
+  for (int i = tid; i < RV_U * WB; i += NT) hcT[i] = 0.f;
   for (int i = tid; i < 2 * W * RV_U; i += NT) cS[i] = 0.f;
   for (int i = tid; i < 4 * W * RV_G; i += NT) part[i] = 0.f;
   if (D > 1) {
@@ -948,16 +950,19 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
     RV_STAMP(d, step, 0);
-    float4 pw[8];                      // first W_mem batch of the q' phase: requested before the (last) gate math, which it does not depend on
-    auto q_prefetch = [&]() {
-      const float* wp = WmemT + (size_t)(16 * (tid >> 6)) * RV_E + 4 * (tid & 63);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
-    };
-    if (D == 1) q_prefetch();
     // ================= gates of this step: the cell product was taken at the end of the previous step on the parent beams
     const int cb = step & 1;                             // cell-state buffer holding the previous step's states
-    for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-quarter sums in fixed order, gate math, cell update
+    // The chunk's resident rows are [keys | U'] = values . [W_mem | A_c] (A_c = the attention layer's context rows), built once
+    // per slab by a GEMM: score_t = keys_t . h as in the reference (128-wide, no q' = W_mem h product per step), and the
+    // attention vector = h . A_h + sum_t alpha_t U'_t (the context never has to pass through the attention layer).
+    float4 pw[8];                      // this thread's whole slice of A_h = W_att[0:128] (8 rows x 4 columns), requested before the gate math
+    auto ah_prefetch = [&]() {
+      const float* wa = d.W_att + (size_t)(8 * (tid >> 5)) * RV_U + 4 * (tid & 31);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
+    };
+    if (D == 1) ah_prefetch();
+    for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
       const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
 #pragma unroll
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
-      if (D > 1) h0T[u * WB + w] = hh; else hcT[u * WB + w] = hh;
+      if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
     }
     __syncthreads();
     if (D > 1) {
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         for (int w = 0; w < W; ++w)
           *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_G + 4 * c4]) = make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
       }
-      q_prefetch();
+      ah_prefetch();
       __syncthreads();
       for (int idx = tid; idx < W * RV_U; idx += NT) {
         const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
@@ -1018,70 +1023,49 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         }
         const float c2 = fmaf(rv_sigmoid(z4[1]), cS1[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
         const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
-        cS1[(cb ^ 1) * W * RV_U + idx] = c2; hcT[u * WB + w] = hh;
+        cS1[(cb ^ 1) * W * RV_U + idx] = c2; hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E;
       }
       __syncthreads();
     }
     RV_STAMP(d, step, 2);
-    // ================= q' = W_mem . h (times log2 e)
+    // ================= attention layer, h part: h . A_h ; thread = (4 columns, 1 of 16 K groups of 8 rows), one batch
     {
-      const int c4 = tid & 63, jg = tid >> 6;               // 8 j-groups of 16 rows of W_memT [128][256]
+      const int d4 = tid & 31, kg = tid >> 5;
       f2 acc[W][2];
 #pragma unroll
       for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-      auto fma8 = [&](const float4* wm, int j0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          float hv[WB];
-          *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + j0 + u) * WB]);
-          if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(16 * jg + j0 + u) * WB + 4]);
+      for (int u = 0; u < 8; ++u) {
+        float hv[WB];
+        *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(8 * kg + u) * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(8 * kg + u) * WB + 4]);
 #pragma unroll
-          for (int w = 0; w < W; ++w) {
-            acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].x, wm[u].y}, acc[w][0]);
-            acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wm[u].z, wm[u].w}, acc[w][1]);
-          }
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{pw[u].x, pw[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{pw[u].z, pw[u].w}, acc[w][1]);
         }
-      };
-      fma8(pw, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        float4 wm[8];
-        const float* wp = WmemT + (size_t)(16 * jg + 8) * RV_E + 4 * c4;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wm[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * RV_E);
-        __builtin_amdgcn_sched_barrier(0);
-        fma8(wm, 8);
       }
 #pragma unroll
-      for (int w = 0; w < W; ++w)
-        *reinterpret_cast<float4*>(&part[(jg * W + w) * RV_E + 4 * c4]) =
+      for (int w = 0; w < W; ++w)    // (the cell-product partial sums in `part` were consumed by the gates above)
+        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_U + 4 * d4]) =
             make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
     }
-    __syncthreads();
-    for (int i = tid; i < W * RV_E; i += NT) {
-      const int w = i >> 8, col = i & 255;
-      float s0 = 0.f;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
-      qp[i] = s0 * LOG2E;
-    }
-    __syncthreads();
-
     RV_STAMP(d, step, 3);
-    // ================= scores from the resident rows: lane sub == w keeps beam w's NIT scores
+
+    // ================= scores from the resident key rows: lane sub == w keeps beam w's NIT scores
     float sc[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) sc[it] = -INFINITY;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      float4 qv[4];
+      float4 qv[2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_E + 4 * sub + 64 * m]);
+      for (int m = 0; m < 2; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_U + 4 * sub + 64 * m]);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         f2 pp = f2{0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 2; ++m) {
           pp = __builtin_elementwise_fma(f2{vr[it][m].x, vr[it][m].y}, f2{qv[m].x, qv[m].y}, pp);
           pp = __builtin_elementwise_fma(f2{vr[it][m].z, vr[it][m].w}, f2{qv[m].z, qv[m].w}, pp);
         }
@@ -1114,96 +1098,50 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       for (int it = 0; it < NIT; ++it) sc[it] = m == -INFINITY ? nanv : sc[it] * f;   // alignments of beam `sub` on this stream's rows
     }
     RV_STAMP(d, step, 5);
-    // ================= context = sum_t alpha_t * values_t, one beam at a time (16-register accumulator)
+    // ================= attention-layer context part = sum_t alpha_t * U'_t, one beam at a time (8-register accumulator)
     {
-      float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (16 * 16 * 4));
+      float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (4 * 2 * 16 * 4));
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        f2 a[8];
+        f2 a[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = f2{0.f, 0.f};
+        for (int i = 0; i < 4; ++i) a[i] = f2{0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const float al = row_bcast(sc[it], w);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            a[2 * m] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][m].x, vr[it][m].y}, a[2 * m]);
-            a[2 * m + 1] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][m].z, vr[it][m].w}, a[2 * m + 1]);
+          for (int m = 0; m < 2; ++m) {
+            a[2 * m] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][2 + m].x, vr[it][2 + m].y}, a[2 * m]);
+            a[2 * m + 1] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][2 + m].z, vr[it][2 + m].w}, a[2 * m + 1]);
           }
         }
-        // fold the wave's 4 streams (same columns) in ONE LDS round trip: every row parks its 4 column blocks,
-        // row r then sums block m = r over the 4 streams in fixed order.  DS operations of one wave execute in
-        // issue order, so the reads see the writes without a wait in between.
+        // fold the wave's 4 streams (same columns) in ONE LDS round trip: every row parks its 2 column blocks, rows 0 and 1
+        // then sum one block each over the 4 streams in fixed order.  DS operations of one wave execute in issue order, so
+        // the reads see the writes without a wait in between.
 #pragma unroll
-        for (int m = 0; m < 4; ++m) slab[(row * 4 + m) * 16 + sub] = make_float4(a[2 * m].x, a[2 * m].y, a[2 * m + 1].x, a[2 * m + 1].y);
+        for (int m = 0; m < 2; ++m) slab[(row * 2 + m) * 16 + sub] = make_float4(a[2 * m].x, a[2 * m].y, a[2 * m + 1].x, a[2 * m + 1].y);
         asm volatile("" ::: "memory");
-        const float4 p0 = slab[(0 * 4 + row) * 16 + sub], p1 = slab[(1 * 4 + row) * 16 + sub];
-        const float4 p2 = slab[(2 * 4 + row) * 16 + sub], p3 = slab[(3 * 4 + row) * 16 + sub];
-        *reinterpret_cast<float4*>(&part[(wv * W + w) * RV_E + 4 * sub + 64 * row]) =
-            make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        if (row < 2) {
+          const float4 p0 = slab[(0 * 2 + row) * 16 + sub], p1 = slab[(1 * 2 + row) * 16 + sub];
+          const float4 p2 = slab[(2 * 2 + row) * 16 + sub], p3 = slab[(3 * 2 + row) * 16 + sub];
+          *reinterpret_cast<float4*>(&ctxp[(wv * W + w) * RV_U + 4 * sub + 64 * row]) =
+              make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        }
         asm volatile("" ::: "memory");
       }
-    }
-    float4 pa[8];                      // first W_att batch of the attention layer: in flight across the barrier and the cross-wave context sum
-    {
-      const float* wa = d.W_att + (size_t)(24 * (tid >> 5)) * RV_U + 4 * (tid & 31);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pa[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
     }
     __syncthreads();
     RV_STAMP(d, step, 6);
-    for (int i = tid; i < W * RV_E; i += NT) {              // fixed-order reduction over the 8 waves
-      const int w = i >> 8, col = i & 255;
-      float s0 = 0.f;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) s0 += part[(g * W + w) * RV_E + col];
-      hcT[(RV_U + col) * WB + w] = s0;
-    }
-    __syncthreads();
-
-    RV_STAMP(d, step, 7);
-    // ================= attention = [h ; context] . W_att ; thread = (4 columns, 1 of 16 K-groups of 24)
-    {
-      const int d4 = tid & 31, kg = tid >> 5;
-      f2 acc[W][2];
-#pragma unroll
-      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
-      auto fma8 = [&](const float4* wa4, int k0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          float hv[WB];
-          *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + k0 + u) * WB]);
-          if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(24 * kg + k0 + u) * WB + 4]);
-#pragma unroll
-          for (int w = 0; w < W; ++w) {
-            acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wa4[u].x, wa4[u].y}, acc[w][0]);
-            acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{wa4[u].z, wa4[u].w}, acc[w][1]);
-          }
-        }
-      };
-      fma8(pa, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-      for (int k0 = 8; k0 < 24; k0 += 8) {
-        float4 wa4[8];
-        const float* wa = d.W_att + (size_t)(24 * kg + k0) * RV_U + 4 * d4;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wa4[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
-        __builtin_amdgcn_sched_barrier(0);
-        fma8(wa4, k0);
-      }
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_U + 4 * d4]) =
-            make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
-    }
-    __syncthreads();
-    for (int i = tid; i < W * RV_U; i += NT) {
+    for (int i = tid; i < W * RV_U; i += NT) {              // attention vector = h . A_h (16 K groups) + context part (8 waves), fixed order
       const int w = i >> 7, col = i & 127;
       float s0 = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
-      att[i] = s0; attT[col * WB + w] = s0;
+      float s1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s1 += ctxp[(g * W + w) * RV_U + col];
+      const float av = s0 + s1;
+      att[i] = av; attT[col * WB + w] = av;
     }
     __syncthreads();
     RV_STAMP(d, step, 8);
@@ -1445,35 +1383,35 @@ __global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict
 }  // namespace
 
 template <int W, int D>
-static void launch_persist_wd(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+static void launch_persist_wd(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                               const float* Wcat1, const float* bdec1, hipStream_t s) {
   const size_t shm = sizeof(float) * PersistLds(W, D).total;
-  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
-  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
-  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1);
+  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
+  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
+  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
 }
 template <int W>
-static void launch_persist_w(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+static void launch_persist_w(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                              const float* Wcat1, const float* bdec1, hipStream_t s) {
   if constexpr (W <= 5) {
-    if (d.depth > 1) { launch_persist_wd<W, 2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); return; }
+    if (d.depth > 1) { launch_persist_wd<W, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); return; }
   }
-  launch_persist_wd<W, 1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s);
+  launch_persist_wd<W, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s);
 }
 bool dec_persist_supported(const DecState& d) {
   return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
 }
-void launch_dec_persist(const DecState& d, const float* WmemT, const float* Wcat, const float* Wtok, const float* bdec,
+void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                         const float* Wcat1, const float* bdec1, hipStream_t s) {
   switch (d.W) {
-    case 1: launch_persist_w<1>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 2: launch_persist_w<2>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 3: launch_persist_w<3>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 4: launch_persist_w<4>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 5: launch_persist_w<5>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 6: launch_persist_w<6>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 7: launch_persist_w<7>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    default: launch_persist_w<8>(d, WmemT, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 1: launch_persist_w<1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 2: launch_persist_w<2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 3: launch_persist_w<3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 4: launch_persist_w<4>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 5: launch_persist_w<5>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 6: launch_persist_w<6>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 7: launch_persist_w<7>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    default: launch_persist_w<8>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
   }
   hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
 }

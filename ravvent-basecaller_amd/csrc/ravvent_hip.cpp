@@ -58,6 +58,8 @@ struct RvContext {
   float* d_Wp = nullptr;                    // derived: input kernels of encoder layers >= 1 as MFMA B fragments, [enc][layer-1][dir][131072]
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
+  float* d_Wmp = nullptr;                   // derived: [W_mem | A_c] [256][256] (A_c = W_att rows 128..383): projection of the attention memory for the persistent decode
+  float* mem2 = nullptr;                    // [B,Tm,256] = enc_out . Wmp: keys | attention-layer image of the values
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
 
@@ -443,8 +445,17 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if (h->lpersist) {
     part[0] = d; part[0].part = 0; parts.n = 1;
     if (greedy) HIPCHK(h, hipMemsetAsync(d.nfin, 0, 2 * sizeof(int), s));   // chunks-finished count and latest first-finish step
+    {   // attention memory in the form the persistent decode keeps on chip: [keys | U'] = enc_out . [W_mem | A_c]
+      GemmArgs g{};
+      g.A = h->enc_out; g.lda = RV_E; g.Bm = h->d_Wmp; g.ldb = RV_E; g.C = h->mem2; g.ldc = RV_E;
+      g.M = B * Tm; g.N = RV_E; g.K = RV_E;
+      g.xcd_remap = 1;
+      Scope sc(h, "gemm_memory");
+      launch_gemm_f32(g, false, s);
+    }
+    d.values = h->mem2; part[0].values = h->mem2;
     Scope sc(h, "dec_persist", nullptr, true);
-    launch_dec_persist(d, h->d_WmemT, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b,
+    launch_dec_persist(d, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b,
                        d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, s);
   } else if (h->opt_graph && h->opt_profile != 2) {
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
@@ -558,6 +569,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
+  TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
@@ -579,6 +591,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
       for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
   TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
   TRY(dalloc(h, &h->keys, B * Tm * RV_U));
+  TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
   DecState& d = h->dec_st;
   if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
   if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
@@ -676,6 +689,17 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           float* dst = h->d_Wp + ((size_t)(e * (h->cfg.enc_depth - 1) + (l - 1)) * 2 + dr) * RV_E * RV_G;
           HIPCHK(h, hipMemcpy(dst, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+    {   // [W_mem | A_c] [256][256]: column block 0 = W_mem (keys), column block 1 = rows 128..383 of the attention layer
+        // (its context part), so that enc_out . Wmp = [keys | image of the values under the attention layer]
+      const size_t mo = (size_t)(h->W_mem - h->d_w), ao = (size_t)(h->W_att - h->d_w) + (size_t)RV_U * RV_U;
+      std::vector<float> wmp((size_t)RV_E * RV_E);
+      for (int kk = 0; kk < RV_E; ++kk)
+        for (int n = 0; n < RV_U; ++n) {
+          wmp[(size_t)kk * RV_E + n] = blob[mo + (size_t)kk * RV_U + n];
+          wmp[(size_t)kk * RV_E + RV_U + n] = blob[ao + (size_t)kk * RV_U + n];
+        }
+      HIPCHK(h, hipMemcpy(h->d_Wmp, wmp.data(), wmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
     std::vector<float> m((size_t)RV_U * RV_E);
     for (int i = 0; i < RV_E; ++i)

@@ -13,8 +13,8 @@ for _ in range(3):
     bc.beam_search_prediction(x, 5, 48)
     ts = bc.get_tensor("dbg_stamps")
     if os.environ.get("RV_PERSIST", "1") != "0":
-        pn = [("gates", 0, 2), ("qprime", 2, 3), ("scores", 3, 4), ("softmax", 4, 5), ("context", 5, 6), ("ctx-reduce", 6, 7),
-              ("att-layer", 7, 8), ("logits", 8, 9), ("beam||cell-GEMV", 9, 10)]
+        pn = [("gates", 0, 2), ("att-h", 2, 3), ("scores", 3, 4), ("softmax", 4, 5), ("context", 5, 6), ("merge", 6, 8),
+              ("logits", 8, 9), ("beam||cell-GEMV", 9, 10)]
         print(" ".join(f"{n}={ts[j]-ts[i]:.0f}" for n, i, j in pn), "step total", ts[10] - ts[0])
         continue
     names = ["entry", "prologue", "qprime", "sweep", "merge", "E att", "F logits", "G beam", "H/end"]
