@@ -114,10 +114,11 @@ void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int st
 // Persistent decode (Luong beam search with W <= 8, W <= 5 with two stacked cells; greedy search; no taps): the whole loop in
 // one launch, the chunk's attention memory resident in registers; also writes S_dev[0..1].  d.values must point at the
 // PROJECTED memory [B,Tm,256] = enc_output . [W_mem | A_c] (keys | attention-layer image of the values).
-// Wcat1 / bdec1: second cell ([W_1;U_1], b_1) or null.
+// One cell: Wcat = [W_a ; U + A_h W_a] and Nh = A_h W_fc [128,V] (the attention layer's h part folded into the weights);
+// two cells: Wcat = [W_a ; U_0], Wcat1 / bdec1 = second cell ([W_1;U_1], b_1), Nh unused.
 bool dec_persist_supported(const DecState& d);
 void launch_dec_persist(const DecState& d, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
-                        const float* bdec /*[512]*/, const float* Wcat1, const float* bdec1, hipStream_t s);
+                        const float* bdec /*[512]*/, const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
 struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; };
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s);   // S_dev[0] = max_g S_g, S_dev[1+g] = S_g

@@ -864,7 +864,8 @@ struct PersistLds {
     qp = o; o += W * RV_U;             // h * log2(e): the score query
     part = o; o += 4 * W * RV_G;       // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
                                        // layer's h-part partial sums [16][W][128] (after the gates -> merge)
-    ctxp = o; o += 8 * W * RV_U;       // context partial sums of the 8 waves [8][W][128]
+    ctxp = part;                       // context partial sums of the 8 waves [8][W][128]: one cell -> inside `part` (idle between
+    if (D > 1) { ctxp = o; o += 8 * W * RV_U; }   // the gates and the end of the step); two cells -> own space (`part` holds h . A_h then)
     fold = o; o += 8 * 4 * 2 * 16 * 4; // wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
                                        // second cell's recurrent partial sums [3][W][512] between the end of a step and its gates
     hcT = o; o += RV_U * WB;           // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
@@ -885,7 +886,8 @@ struct PersistLds {
 template <int W, int NIT, int D>
 __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
                                                       const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/,
-                                                      const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1) {
+                                                      const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1,
+                                                      const float* __restrict__ Nh /*D == 1: A_h . W_fc [128,V]*/) {
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D);
@@ -894,6 +896,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
   float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (spans ctxp + fold)
   __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
+  __shared__ float s_nh[D == 1 ? RV_U * RV_MAX_VOCAB : 1];
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
 
@@ -932,6 +935,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     b1s[tid] = bdec1[tid];
   }
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
+  if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[i] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
   if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
   if (tid < WB) {
     s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
@@ -954,14 +958,16 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     const int cb = step & 1;                             // cell-state buffer holding the previous step's states
     // The chunk's resident rows are [keys | U'] = values . [W_mem | A_c] (A_c = the attention layer's context rows), built once
     // per slab by a GEMM: score_t = keys_t . h as in the reference (128-wide, no q' = W_mem h product per step), and the
-    // attention vector = h . A_h + sum_t alpha_t U'_t (the context never has to pass through the attention layer).
-    float4 pw[8];                      // this thread's whole slice of A_h = W_att[0:128] (8 rows x 4 columns), requested before the gate math
+    // attention vector = h . A_h + ctx' with ctx' = sum_t alpha_t U'_t (the context never has to pass through the attention
+    // layer).  With ONE decoder cell the h part is folded into the weights at load time as well: the cell product of the
+    // next step is [ctx' | h] . [W_a ; U + A_h W_a] and the logits are ctx' . W_fc + h . (A_h W_fc) + b, so no attention-layer
+    // product is left in the step.  With two cells (cell 0 would need h_1 as a third input block) h . A_h stays explicit.
+    float4 pw[8];                      // D == 2: this thread's whole slice of A_h = W_att[0:128] (8 rows x 4 columns), requested before the gate math
     auto ah_prefetch = [&]() {
       const float* wa = d.W_att + (size_t)(8 * (tid >> 5)) * RV_U + 4 * (tid & 31);
 #pragma unroll
       for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
     };
-    if (D == 1) ah_prefetch();
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
       const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
@@ -1028,8 +1034,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       __syncthreads();
     }
     RV_STAMP(d, step, 2);
-    // ================= attention layer, h part: h . A_h ; thread = (4 columns, 1 of 16 K groups of 8 rows), one batch
-    {
+    // ================= (two cells) attention layer, h part: h . A_h ; thread = (4 columns, 1 of 16 K groups of 8 rows), one batch
+    if (D > 1) {
       const int d4 = tid & 31, kg = tid >> 5;
       f2 acc[W][2];
 #pragma unroll
@@ -1132,11 +1138,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     __syncthreads();
     RV_STAMP(d, step, 6);
-    for (int i = tid; i < W * RV_U; i += NT) {              // attention vector = h . A_h (16 K groups) + context part (8 waves), fixed order
+    for (int i = tid; i < W * RV_U; i += NT) {              // ctx' (8 waves, fixed order) [+ h . A_h (16 K groups) = attention vector when D == 2]
       const int w = i >> 7, col = i & 127;
       float s0 = 0.f;
+      if (D > 1) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+        for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+      }
       float s1 = 0.f;
 #pragma unroll
       for (int g = 0; g < 8; ++g) s1 += ctxp[(g * W + w) * RV_U + col];
@@ -1153,6 +1161,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         float p = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) p = fmaf(att[w * RV_U + 8 * i + s8], s_wfc[(8 * i + s8) * V + v], p);
+        if (D == 1) {                                       // + h . (A_h W_fc)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) p = fmaf(qp[w * RV_U + 8 * i + s8], s_nh[(8 * i + s8) * V + v], p);
+        }
         p += dpp<0xB1>(p);    // quad_perm [1,0,3,2]
         p += dpp<0x4E>(p);    // quad_perm [2,3,0,1]
         p += dpp<0x141>(p);   // row_half_mirror: the other quad of this 8-lane group
@@ -1384,34 +1396,35 @@ __global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict
 
 template <int W, int D>
 static void launch_persist_wd(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
-                              const float* Wcat1, const float* bdec1, hipStream_t s) {
+                              const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
   const size_t shm = sizeof(float) * PersistLds(W, D).total;
-  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
-  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
-  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1);
+  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
+  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
+  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
 }
 template <int W>
 static void launch_persist_w(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
-                             const float* Wcat1, const float* bdec1, hipStream_t s) {
+                             const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
   if constexpr (W <= 5) {
-    if (d.depth > 1) { launch_persist_wd<W, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); return; }
+    if (d.depth > 1) { launch_persist_wd<W, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
-  launch_persist_wd<W, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s);
+  launch_persist_wd<W, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
+  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
   return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
-                        const float* Wcat1, const float* bdec1, hipStream_t s) {
+                        const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
   switch (d.W) {
-    case 1: launch_persist_w<1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 2: launch_persist_w<2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 3: launch_persist_w<3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 4: launch_persist_w<4>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 5: launch_persist_w<5>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 6: launch_persist_w<6>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    case 7: launch_persist_w<7>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
-    default: launch_persist_w<8>(d, Wcat, Wtok, bdec, Wcat1, bdec1, s); break;
+    case 1: launch_persist_w<1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 2: launch_persist_w<2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 3: launch_persist_w<3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 4: launch_persist_w<4>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 5: launch_persist_w<5>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 6: launch_persist_w<6>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    case 7: launch_persist_w<7>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
+    default: launch_persist_w<8>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
   }
   hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
 }

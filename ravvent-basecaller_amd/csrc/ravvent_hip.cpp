@@ -59,6 +59,8 @@ struct RvContext {
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
   float* d_Wmp = nullptr;                   // derived: [W_mem | A_c] [256][256] (A_c = W_att rows 128..383): projection of the attention memory for the persistent decode
+  float* d_Wcat2 = nullptr;                 // derived (one decoder cell): [W_a ; U + A_h W_a] [256][512]
+  float* d_Nh = nullptr;                    // derived (one decoder cell): A_h W_fc [128][V]
   float* mem2 = nullptr;                    // [B,Tm,256] = enc_out . Wmp: keys | attention-layer image of the values
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
@@ -455,8 +457,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
     d.values = h->mem2; part[0].values = h->mem2;
     Scope sc(h, "dec_persist", nullptr, true);
-    launch_dec_persist(d, h->dec[0].W + (size_t)V * RV_G, h->dec[0].W, h->dec[0].b,
-                       d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, s);
+    launch_dec_persist(d, d.depth > 1 ? h->dec[0].W + (size_t)V * RV_G : h->d_Wcat2, h->dec[0].W, h->dec[0].b,
+                       d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, h->d_Nh, s);
   } else if (h->opt_graph && h->opt_profile != 2) {
     GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
     auto it = h->graphs.find(key);
@@ -570,6 +572,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
+  TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
+  TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
@@ -699,6 +703,29 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           wmp[(size_t)kk * RV_E + RV_U + n] = blob[ao + (size_t)kk * RV_U + n];
         }
       HIPCHK(h, hipMemcpy(h->d_Wmp, wmp.data(), wmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (h->cfg.dec_depth == 1) {
+      // attention = h . A_h + ctx'; its h part is folded into what consumes the attention vector (products in double):
+      // next cell input  [ctx' | h] . [W_a ; U + A_h W_a],  logits  ctx' . W_fc + h . (A_h W_fc) + b
+      const int V = h->cfg.vocab;
+      const size_t wa = (size_t)(h->dec[0].W - h->d_w) + (size_t)V * RV_G, uo = (size_t)(h->dec[0].U - h->d_w);
+      const size_t ah = (size_t)(h->W_att - h->d_w), fc = (size_t)(h->W_fc - h->d_w);
+      std::vector<float> w2((size_t)RV_E * RV_G), nh((size_t)RV_U * RV_MAX_VOCAB, 0.f);
+      for (int i = 0; i < RV_U; ++i)
+        for (int n = 0; n < RV_G; ++n) {
+          w2[(size_t)i * RV_G + n] = blob[wa + (size_t)i * RV_G + n];
+          double acc = blob[uo + (size_t)i * RV_G + n];
+          for (int j = 0; j < RV_U; ++j) acc += (double)blob[ah + (size_t)i * RV_U + j] * (double)blob[wa + (size_t)j * RV_G + n];
+          w2[(size_t)(RV_U + i) * RV_G + n] = (float)acc;
+        }
+      for (int i = 0; i < RV_U; ++i)
+        for (int v = 0; v < V; ++v) {
+          double acc = 0.0;
+          for (int j = 0; j < RV_U; ++j) acc += (double)blob[ah + (size_t)i * RV_U + j] * (double)blob[fc + (size_t)j * V + v];
+          nh[(size_t)i * V + v] = (float)acc;
+        }
+      HIPCHK(h, hipMemcpy(h->d_Wcat2, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpy(h->d_Nh, nh.data(), nh.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
     std::vector<float> m((size_t)RV_U * RV_E);
