@@ -171,6 +171,15 @@ __device__ __forceinline__ float row_bcast(float v, int n) {
     case 6: return dpp<0x156>(v); default: return dpp<0x157>(v);
   }
 }
+// same, source lane n in 0..15
+__device__ __forceinline__ float row_bcast16(float v, int n) {
+  switch (n) {
+    case 0: return dpp<0x150>(v); case 1: return dpp<0x151>(v); case 2: return dpp<0x152>(v); case 3: return dpp<0x153>(v);
+    case 4: return dpp<0x154>(v); case 5: return dpp<0x155>(v); case 6: return dpp<0x156>(v); case 7: return dpp<0x157>(v);
+    case 8: return dpp<0x158>(v); case 9: return dpp<0x159>(v); case 10: return dpp<0x15A>(v); case 11: return dpp<0x15B>(v);
+    case 12: return dpp<0x15C>(v); case 13: return dpp<0x15D>(v); case 14: return dpp<0x15E>(v); default: return dpp<0x15F>(v);
+  }
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -905,18 +914,29 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   const size_t row0 = (size_t)b * W;
   const int steps = d.L - 1;
 
-  // ---- the chunk's attention memory -> registers (once)
-  float4 vr[NIT][4];
+  // ---- the chunk's attention memory -> registers (once).  Keys: the 16 lanes of a stream hold TWO rows at a time, lanes 0-7
+  //      row sid + 32 (2p), lanes 8-15 row sid + 32 (2p + 1), 16 columns each, so that a score is an 8-lane reduction and one
+  //      pass over the registers scores two rows.  U' (the context side): every lane 8 columns of each of the stream's rows.
+  constexpr int NP = (NIT + 1) / 2;
+  const int half = sub >> 3, s8 = sub & 7;
+  float4 kr[NP][4], ur[NIT][2];
   unsigned livebits = 0;
   {
-    const float* vbase = d.values + (size_t)b * Tm * RV_E + 4 * sub;
+    const float* cbase = d.values + (size_t)b * Tm * RV_E;
     const uint8_t* mrow = d.mask + (size_t)b * Tm;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int tc = min(sid + 32 * (2 * p + half), Tm - 1);
+      const float* q = cbase + (size_t)tc * RV_E + 16 * s8;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) kr[p][m] = *reinterpret_cast<const float4*>(q + 4 * m);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int t = sid + 32 * it, tc = min(t, Tm - 1);
-      const float* p = vbase + (size_t)tc * RV_E;
+      const float* q = cbase + (size_t)tc * RV_E + RV_U + 4 * sub;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) vr[it][m] = *reinterpret_cast<const float4*>(p + 64 * m);
+      for (int m = 0; m < 2; ++m) ur[it][m] = *reinterpret_cast<const float4*>(q + 64 * m);
       if (t < Tm && mrow[tc]) livebits |= 1u << it;       // _maybe_mask_score: padded steps never score
     }
   }
@@ -1058,25 +1078,30 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     RV_STAMP(d, step, 3);
 
-    // ================= scores from the resident key rows: lane sub == w keeps beam w's NIT scores
-    float sc[NIT];
+    // ================= scores from the resident key rows: lane w keeps beam w's score of the even row of a pair, lane 8 + w
+    //   that of the odd row
+    float sc[NP];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) sc[it] = -INFINITY;
+    for (int p = 0; p < NP; ++p) sc[p] = -INFINITY;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      float4 qv[2];
+      float4 qv[4];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_U + 4 * sub + 64 * m]);
+      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_U + 16 * s8 + 4 * m]);
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
+      for (int p = 0; p < NP; ++p) {
         f2 pp = f2{0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          pp = __builtin_elementwise_fma(f2{vr[it][m].x, vr[it][m].y}, f2{qv[m].x, qv[m].y}, pp);
-          pp = __builtin_elementwise_fma(f2{vr[it][m].z, vr[it][m].w}, f2{qv[m].z, qv[m].w}, pp);
+        for (int m = 0; m < 4; ++m) {
+          pp = __builtin_elementwise_fma(f2{kr[p][m].x, kr[p][m].y}, f2{qv[m].x, qv[m].y}, pp);
+          pp = __builtin_elementwise_fma(f2{kr[p][m].z, kr[p][m].w}, f2{qv[m].z, qv[m].w}, pp);
         }
-        const float sw = row16_sum(pp.x + pp.y);
-        sc[it] = (sub == w && ((livebits >> it) & 1u)) ? sw : sc[it];
+        float sw = pp.x + pp.y;
+        sw += dpp<0xB1>(sw);    // quad_perm [1,0,3,2]
+        sw += dpp<0x4E>(sw);    // quad_perm [2,3,0,1]
+        sw += dpp<0x141>(sw);   // row_half_mirror: the other quad of this 8-lane half
+        const int it = 2 * p + half;
+        sc[p] = (s8 == w && it < NIT && ((livebits >> it) & 1u)) ? sw : sc[p];
       }
     }
     RV_STAMP(d, step, 4);
@@ -1084,10 +1109,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     {
       float m = -INFINITY;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) m = fmaxf(m, sc[it]);
+      for (int p = 0; p < NP; ++p) m = fmaxf(m, sc[p]);
+      m = fmaxf(m, dpp<0x128>(m));                          // row_ror:8 -- the stream's other half
       float lsum = 0.f;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) { sc[it] = exp2f(sc[it] - m); lsum += sc[it]; }   // stream without live rows: NaN, dropped below
+      for (int p = 0; p < NP; ++p) { sc[p] = exp2f(sc[p] - m); lsum += sc[p]; }   // stream without live rows: NaN, dropped below
+      lsum += dpp<0x128>(lsum);
       if (sub < W) { ml[sid * WB + sub] = m; ml[(32 + sid) * WB + sub] = m == -INFINITY ? 0.f : lsum; }
       __syncthreads();
       if (wv < W) {
@@ -1098,10 +1125,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         if (lane == 0) { mg[wv] = Mg; mg[WB + wv] = Mg == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tot; }
       }
       __syncthreads();
-      const float f = (sub < W && m != -INFINITY) ? exp2f(m - mg[sub]) * mg[WB + sub] : 0.f;
-      const float nanv = (sub < W && mg[WB + sub] != mg[WB + sub]) ? mg[WB + sub] : 0.f;
+      const float f = (s8 < W && m != -INFINITY) ? exp2f(m - mg[s8]) * mg[WB + s8] : 0.f;
+      const float nanv = (s8 < W && mg[WB + s8] != mg[WB + s8]) ? mg[WB + s8] : 0.f;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) sc[it] = m == -INFINITY ? nanv : sc[it] * f;   // alignments of beam `sub` on this stream's rows
+      for (int p = 0; p < NP; ++p) sc[p] = m == -INFINITY ? nanv : sc[p] * f;   // alignments of beam s8 on this half's rows
     }
     RV_STAMP(d, step, 5);
     // ================= attention-layer context part = sum_t alpha_t * U'_t, one beam at a time (8-register accumulator)
@@ -1114,11 +1141,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         for (int i = 0; i < 4; ++i) a[i] = f2{0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const float al = row_bcast(sc[it], w);
+          const float al = row_bcast16(sc[it >> 1], 8 * (it & 1) + w);
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            a[2 * m] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][2 + m].x, vr[it][2 + m].y}, a[2 * m]);
-            a[2 * m + 1] = __builtin_elementwise_fma(f2{al, al}, f2{vr[it][2 + m].z, vr[it][2 + m].w}, a[2 * m + 1]);
+            a[2 * m] = __builtin_elementwise_fma(f2{al, al}, f2{ur[it][m].x, ur[it][m].y}, a[2 * m]);
+            a[2 * m + 1] = __builtin_elementwise_fma(f2{al, al}, f2{ur[it][m].z, ur[it][m].w}, a[2 * m + 1]);
           }
         }
         // fold the wave's 4 streams (same columns) in ONE LDS round trip: every row parks its 2 column blocks, rows 0 and 1
