@@ -326,6 +326,10 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
   }
 
+  if (!h->opt_fuse && c.enc_depth > 1) {   // unfused path only: pre-projected tensors [max_batch, T_max, 2, 512], allocated on first use
+    if (use_raw && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
+    if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
+  }
   // ---- _encode_input (basecaller.py:395-416)
   { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
   // The two encoders are independent until the time-axis concat (basecaller.py:400-405).
@@ -586,10 +590,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
     if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
     if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
   }
-  if (c.enc_depth > 1) {
-    if (use_raw) TRY(dalloc(h, &h->xw[0], B * Tr * 2 * RV_G));
-    if (use_ev) TRY(dalloc(h, &h->xw[1], B * Te * 2 * RV_G));
-  }
+  // (the pre-projected tensors xw of the unfused path -- 4 KB per chunk-timestep -- are allocated on first use: run_encoder)
   for (int e = 0; e < 2; ++e)
     for (int st = 0; st < 2; ++st)
       for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
