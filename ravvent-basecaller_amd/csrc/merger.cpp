@@ -57,6 +57,61 @@ inline double affine(int length, double open, double extend) {   // calc_affine_
   return p;
 }
 
+// The DP swept by anti-diagonals (cells (r, d - r)): no cell of a diagonal depends on another one of it, so the loop over r
+// vectorises (doubles; the same operations in the same order per cell as the row-major loop of the reference, hence
+// bit-identical).  Work arrays are indexed by row: h1 / h2 = scores of diagonals d-1 / d-2, e1 = the column state left by
+// the cell above (diagonal d-1), f = the row state carried along each row, ga / ea = gap-open / gap-extend cost of a gap in
+// A for that row (0 in the last row: free end gaps).  mtab[a*4+b] = match score; ia / ib = letter indices (identity
+// scoring uses a 2-entry table through ia == ib).
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static double fill_diagonals(int lenA, int lenB, double first_gap, double extend, double open2, const int* __restrict__ ia,
+                             const int* __restrict__ ib, const double* __restrict__ mtab, int mstride, double* __restrict__ work,
+                             int* __restrict__ tn, double* __restrict__ score, int* __restrict__ trace) {
+  const int n = lenA + 2, W = lenB + 1;
+  double* h1 = work, *h2 = work + n, *hn = work + 2 * n, *e1 = work + 3 * n, *en = work + 4 * n;
+  double* f = work + 5 * n, *ga = work + 6 * n, *ea = work + 7 * n, *mm = work + 8 * n;
+  double local_max = 0;
+  for (int d = 2; d <= lenA + lenB; ++d) {
+    const int r_lo = d - lenB > 1 ? d - lenB : 1, r_hi = lenA < d - 1 ? lenA : d - 1, r_lastcol = d - lenB;
+    {   // column state of column d-1 before row 1 (used by cell (1, d-1)): calc_affine_penalty(d-1, 2*open, extend)
+      double p = open2 + extend * (d - 1); p -= extend; e1[0] = p;
+    }
+#pragma clang loop vectorize(enable) interleave(disable)
+    for (int r = r_lo; r <= r_hi; ++r) mm[r] = mtab[ia[r - 1] * mstride + ib[d - r - 1]];
+#pragma clang loop vectorize(enable) interleave(disable)
+    for (int r = r_lo; r <= r_hi; ++r) {
+      const double nogap = h2[r - 1] + mm[r];
+      const double row_open = h1[r] + ga[r], row_extend = f[r] + ea[r];
+      const double rs = row_open > row_extend ? row_open : row_extend;
+      const bool lastcol = r == r_lastcol;               // column lenB: free end gaps in B
+      const double col_open = h1[r - 1] + (lastcol ? 0.0 : first_gap), col_extend = e1[r - 1] + (lastcol ? 0.0 : extend);
+      const double cs = col_open > col_extend ? col_open : col_extend;
+      double b = cs > rs ? cs : rs;
+      b = nogap > b ? nogap : b;
+      f[r] = rs; en[r] = cs; hn[r] = b < 0 ? 0.0 : b;
+      // pairwise2.rint(x) = int(x * 1000 + 0.5); rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y))
+      const int ro = (int)(row_open * 1000 + 0.5), re = (int)(row_extend * 1000 + 0.5);
+      const int co = (int)(col_open * 1000 + 0.5), ce = (int)(col_extend * 1000 + 0.5), ng = (int)(nogap * 1000 + 0.5);
+      const int rr = ro > re ? ro : re, cr = co > ce ? co : ce;
+      int br = rr > cr ? rr : cr; br = ng > br ? ng : br;
+      int t = ng == br ? 2 : 0;
+      t += rr == br ? (ro == rr ? 1 : 0) + (re == rr ? 8 : 0) : 0;
+      t += cr == br ? (co == cr ? 4 : 0) + (ce == cr ? 16 : 0) : 0;
+      tn[r] = t;
+    }
+    for (int r = r_lo; r <= r_hi; ++r) {                  // (best score = max over the clipped cells: it starts at 0 in the reference too)
+      score[(size_t)r * W + d - r] = hn[r]; trace[(size_t)r * W + d - r] = tn[r];
+      local_max = local_max > hn[r] ? local_max : hn[r];
+    }
+    // rotate: d-1 -> d-2, d -> d-1; the border cells (0, d) and (d, 0) of the new diagonal d are zero
+    hn[0] = 0.0; if (d <= lenA) hn[d] = 0.0;
+    if (r_lo > 1) hn[r_lo - 1] = 0.0;                     // (row r_lo-1 has no cell on this diagonal any more: beyond column lenB)
+    double* t = h2; h2 = h1; h1 = hn; hn = t;
+    double* te = e1; e1 = en; en = te;
+  }
+  return local_max;
+}
+
 struct Start { double score; int row, col; };
 struct Item { std::string a, b; int end; bool has_end; int row, col; bool col_gap; int trace; };
 struct Aligned { std::string a, b; double score; int begin, end; };
@@ -67,8 +122,8 @@ struct Aligner {
   ScoreSet sc;
   std::vector<double> score;     // (lenA+1) x (lenB+1)
   std::vector<int> trace;        // -1 = None (border)
-  std::vector<double> col_score;
-  std::vector<int> bidx;
+  std::vector<double> dbuf, itab;  // per-diagonal work arrays of fill(); identity match table
+  std::vector<int> tbuf, ia, ib;
   std::vector<Start> starts;
   double best = 0;
   int W = 0;
@@ -81,65 +136,45 @@ struct Aligner {
     return sc.m[base_index(a)][base_index(b)];
   }
 
-  void fill() {                  // _make_score_matrix_fast: local, penalize_end_gaps (False, False)
+  void fill() {                  // _make_score_matrix_fast: local, penalize_end_gaps (False, False); swept by anti-diagonals
     W = lenB + 1;
-    score.resize((size_t)(lenA + 1) * W);
-    trace.resize((size_t)(lenA + 1) * W);
-    col_score.resize(lenB + 1);
-    bidx.resize(lenB + 1);
+    score.assign((size_t)(lenA + 1) * W, 0.0);
+    trace.assign((size_t)(lenA + 1) * W, -1);
     const double open = sc.open, extend = sc.extend;
     const double first_gap = affine(1, open, extend);
-    double local_max = 0;
-    for (int c = 0; c <= lenB; ++c) { score[c] = 0.0; trace[c] = -1; }
-    col_score[0] = 0.0;
-    for (int i = 1; i <= lenB; ++i) col_score[i] = affine(i, 2 * open, extend);
-    // Cells of one row form a dependent chain (row_score and the left neighbour), ~25 cycles each; four rows are
-    // swept as a skewed wavefront so that four independent chains are in flight.  Every cell still sees exactly
-    // the operands the row-major loop of the reference gives it.
-    for (int c = 1; c <= lenB; ++c) bidx[c] = sc.matrix ? base_index(B[c - 1]) : 0;
-    for (int r0 = 1; r0 <= lenA; r0 += 4) {
-      const int nr = std::min(4, lenA - r0 + 1);
-      double row_score[4];
-      for (int k = 0; k < nr; ++k) {
-        row_score[k] = affine(r0 + k, 2 * open, extend);
-        score[(size_t)(r0 + k) * W] = 0.0; trace[(size_t)(r0 + k) * W] = -1;
-      }
-      for (int d = 0; d < lenB + nr - 1; ++d) {
-        for (int k = 0; k < nr; ++k) {
-          const int col = d - k + 1;
-          if (col < 1 || col > lenB) continue;
-          const int row = r0 + k;
-          const double* up = &score[(size_t)(row - 1) * W];
-          double* cur = &score[(size_t)row * W];
-          const char a = A[row - 1];
-          const double mm = sc.matrix ? sc.m[base_index(a)][bidx[col]] : (a == B[col - 1] ? sc.match : sc.mismatch);
-          const double nogap = up[col - 1] + mm;
-          double row_open, row_extend, col_open, col_extend;
-          if (row == lenA) { row_open = cur[col - 1]; row_extend = row_score[k]; }
-          else { row_open = cur[col - 1] + first_gap; row_extend = row_score[k] + extend; }
-          const double rs = row_open > row_extend ? row_open : row_extend;
-          row_score[k] = rs;
-          if (col == lenB) { col_open = up[col]; col_extend = col_score[col]; }
-          else { col_open = up[col] + first_gap; col_extend = col_score[col] + extend; }
-          const double cs = col_open > col_extend ? col_open : col_extend;
-          col_score[col] = cs;
-          double b = cs > rs ? cs : rs;
-          b = nogap > b ? nogap : b;
-          local_max = local_max > b ? local_max : b;
-          cur[col] = b < 0 ? 0.0 : b;
-          // rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y)): five conversions per cell instead of eight
-          const long long ro = rint1000(row_open), re = rint1000(row_extend), co = rint1000(col_open), ce = rint1000(col_extend);
-          const long long ng = rint1000(nogap);
-          const long long rr = ro > re ? ro : re, cr = co > ce ? co : ce;
-          long long br = rr > cr ? rr : cr; br = ng > br ? ng : br;
-          int t = ng == br ? 2 : 0;
-          if (rr == br) t += (ro == rr ? 1 : 0) + (re == rr ? 8 : 0);
-          if (cr == br) t += (co == cr ? 4 : 0) + (ce == cr ? 16 : 0);
-          trace[(size_t)row * W + col] = t;
-        }
-      }
+    const int n = lenA + 2;
+    dbuf.assign((size_t)9 * n, 0.0);
+    double* f = &dbuf[5 * n], *ga = &dbuf[6 * n], *ea = &dbuf[7 * n];
+    tbuf.assign(n, 0);
+    ia.resize(lenA); ib.resize(lenB);
+    double mtab[16];
+    if (sc.matrix) {
+      for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) mtab[i * 4 + k] = sc.m[i][k];
+      for (int i = 0; i < lenA; ++i) ia[i] = base_index(A[i]);
+      for (int i = 0; i < lenB; ++i) ib[i] = base_index(B[i]);
+    } else {     // identity scoring on arbitrary letters: index = (a != b) through a per-pair comparison below
+      for (int i = 0; i < lenA; ++i) ia[i] = (unsigned char)A[i];
+      for (int i = 0; i < lenB; ++i) ib[i] = (unsigned char)B[i];
     }
-    best = local_max;
+    for (int r = 1; r <= lenA; ++r) {
+      f[r] = affine(r, 2 * open, extend);                 // row state before column 1
+      ga[r] = r == lenA ? 0.0 : first_gap; ea[r] = r == lenA ? 0.0 : extend;
+    }
+    if (sc.matrix) {
+      best = fill_diagonals(lenA, lenB, first_gap, extend, 2 * open, ia.data(), ib.data(), mtab, 4, dbuf.data(), tbuf.data(), score.data(), trace.data());
+    } else {
+      // identity: a 256 x 256 table would defeat the purpose; map letters to 0..3 when both strings are ACGT, else fall back to codes
+      // of first occurrence (at most 50 distinct letters in two 25-letter strings -> table of 64 x 64)
+      int code[256]; for (int i = 0; i < 256; ++i) code[i] = -1;
+      int ncode = 0;
+      for (int i = 0; i < lenA; ++i) { if (code[ia[i]] < 0) code[ia[i]] = ncode++; }
+      for (int i = 0; i < lenB; ++i) { if (code[ib[i]] < 0) code[ib[i]] = ncode++; }
+      for (int i = 0; i < lenA; ++i) ia[i] = code[ia[i]];
+      for (int i = 0; i < lenB; ++i) ib[i] = code[ib[i]];
+      itab.assign((size_t)ncode * ncode, sc.mismatch);
+      for (int i = 0; i < ncode; ++i) itab[(size_t)i * ncode + i] = sc.match;
+      best = fill_diagonals(lenA, lenB, first_gap, extend, 2 * open, ia.data(), ib.data(), itab.data(), ncode, dbuf.data(), tbuf.data(), score.data(), trace.data());
+    }
   }
 
   void find_start(std::vector<Start>& st) {
