@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ravvent_basecaller_amd as rv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(123)
+rng = np.random.default_rng(int(os.environ.get("RV_STRESS_SEED", "123")))
 bad = 0
 for case in range(n):
     mode = ("joint", "raw", "event")[int(rng.integers(0, 3))]
