@@ -121,6 +121,8 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.
  *                       The step_ids / parent_ids / step_scores taps of a chunk then end at its own last
  *                       step instead of the slab's),
+ *          "persist_taps" (0/1, default 0: the persistent decode also records every step's logits [S,B,W,V] for
+ *                       rv_get_tensor("step_logits"); rows of a chunk beyond its own last step ("chunk_steps") are not written),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around
  *                       the graph as a whole; 2: no graph, events around every kernel; 3: events around the decode
  *                       launch only -- the persistent decode kernel or the decode graph). */
@@ -130,7 +132,8 @@ int rv_set_option(rv_handle h, const char* key, int32_t value);
  *   "enc_output" [B,T_m,2u]   _encode_input's output              basecaller.py:405
  *   "mask"       [B,T_m]      input_mask (1.0 / 0.0)              basecaller.py:406
  *   "keys"       [B,T_m,d]    attention keys after setup_memory   basecaller.py:303
- *   "step_logits"     [S,B,W,V]   (needs debug_taps)
+ *   "step_logits"     [S,B,W,V]   (needs debug_taps, or persist_taps on the persistent decode)
+ *   "chunk_steps"     [B]         steps each chunk ran in the persistent decode (its beams all finished there)
  *   "step_alignments" [S,B,W,T_m] (needs debug_taps)
  *   "step_ids" / "parent_ids" / "step_scores" [S,B,W]
  * n_written receives the element count; fails with RV_EINVAL if dst is too small. */

@@ -33,7 +33,7 @@ void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s)
 // layers >= 1 with x . W + b computed inside the kernel (MFMA waves beside the recurrence waves): a.x = [B,T,256] activations,
 // a.Wp / a.bias per direction
 void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
-void configure_rec_kernels();
+hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the fused-projection kernels; first error or hipSuccess
 
 // ---------------------------------------------------------------- K0/K2: fp32 MFMA GEMM
 struct GemmArgs {
@@ -104,7 +104,7 @@ struct DecState {
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3
   int dbg_stop;           // diagnostic builds only: leave k_dec_attend after phase N (0 = run everything)
 };
-void configure_decode_kernels();   // per-device dynamic-LDS opt-in; call after hipSetDevice
+hipError_t configure_decode_kernels();   // per-device dynamic-LDS opt-in; call after hipSetDevice; first error or hipSuccess
 void launch_dec_init(const DecState& d, hipStream_t s);
 // layer: which stacked cell; Wtok (one-hot embedding rows) is non-null for layer 0 only
 void launch_dec_cell(const DecState& d, int layer, const float* WcatT /*[512,256] = ([W_in;U])^T*/, const float* Wtok /*[V,512]*/,

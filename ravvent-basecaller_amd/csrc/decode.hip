@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       if (d.greedy) {                  // GreedyEmbeddingSampler: argmax of the raw logits (W == 1)
         if (cand) { val = lg[v]; d.step_logits[((size_t)step * d.B + b) * V + v] = val; }
       } else if (cand) {
+        if (d.step_logits) d.step_logits[(((size_t)step * d.B + b) * W + w) * V + v] = lg[w * RV_MAX_VOCAB + v];   // debug tap (option persist_taps)
         float m = lg[w * RV_MAX_VOCAB];
         for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
         float ssum = 0.f;
@@ -1244,9 +1245,17 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           d.step_ids[(size_t)step * d.B + b] = my_word;
           s_tok[0] = my_word; s_fin[0] = nf; s_parent[0] = 0;
           if (nf && !pf) { s_len[0] = step + 1; atomicMax(&d.nfin[1], step + 1); __threadfence(); atomicAdd(&d.nfin[0], 1); }
+          // writer: atomicMax(step) -> fence -> atomicAdd(count); reader: count, ACQUIRE fence, then the step, so a reader that
+          // sees every chunk counted also sees every chunk's first-finish step (the two words sit in different L2 channels).
+          // The acquire fence is only paid once the count is complete (the last few steps of the slab).
           const int cnt = __hip_atomic_load(&d.nfin[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int sg = __hip_atomic_load(&d.nfin[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_allfin = nf && cnt >= d.B && step + 1 >= sg;
+          int stop = 0;
+          if (nf && cnt >= d.B) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int sg = __hip_atomic_load(&d.nfin[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stop = step + 1 >= sg;
+          }
+          s_allfin = stop;
         }
       } else {
       if (lane < W) {      // all reads of the old bookkeeping happened above (same wave, program order)
@@ -1439,7 +1448,7 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
 }
 bool dec_persist_supported(const DecState& d) {
   if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
-  return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (d.greedy ? d.W == 1 : !d.step_logits);
+  return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                         const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
@@ -1512,10 +1521,12 @@ void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int st
 // Kernels that use more than the default dynamic-LDS limit opt in once per device (called by rv_create
 // after hipSetDevice): sized for the largest shapes the library accepts (T_m <= 352).
 template <int W>
-static void configure_w() {
+static hipError_t configure_w() {
   constexpr int cap = 160 * 1024 - 10 * 1024;    // leave room for the kernels' static LDS
-  auto opt = [](const void* f, size_t bytes) {
-    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < (size_t)cap ? bytes : (size_t)cap));
+  hipError_t first = hipSuccess;
+  auto opt = [&](const void* f, size_t bytes) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < (size_t)cap ? bytes : (size_t)cap));
+    if (e != hipSuccess && first == hipSuccess) first = e;
   };
   opt(reinterpret_cast<const void*>(&k_dec_attend<W, 2, 8>), sizeof(float) * AttLds(W, 64, false).total);
   opt(reinterpret_cast<const void*>(&k_dec_attend<W, 7, 28>), sizeof(float) * AttLds(W, 224, false).total);
@@ -1530,12 +1541,15 @@ static void configure_w() {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 2>), sizeof(float) * PersistLds(W, 2).total);
   }
+  return first;
 }
-void configure_decode_kernels() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * CELL_LDS_FLOATS));
-  configure_w<1>(); configure_w<2>(); configure_w<3>(); configure_w<4>();
-  configure_w<5>(); configure_w<6>(); configure_w<7>(); configure_w<8>();
+hipError_t configure_decode_kernels() {
+  hipError_t first = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_cell), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(sizeof(float) * CELL_LDS_FLOATS));
+  for (hipError_t e : {configure_w<1>(), configure_w<2>(), configure_w<3>(), configure_w<4>(),
+                       configure_w<5>(), configure_w<6>(), configure_w<7>(), configure_w<8>()})
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  return first;
 }
 
 void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s) {

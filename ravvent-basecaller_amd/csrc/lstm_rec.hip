@@ -422,12 +422,15 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s) {
     default: launch_proj<8>(a, s); break;
   }
 }
-void configure_rec_kernels() {
+hipError_t configure_rec_kernels() {
   const int shm = (int)(sizeof(float) * (2 * 8 * RV_U + 2 * 16 * RV_G + RV_G + 2 * 16 * 260));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<4>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_rec_proj<8>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  hipError_t first = hipSuccess;
+  for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_proj<1>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<4>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8>)}) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  }
+  return first;
 }
 
 void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s) {

@@ -86,6 +86,7 @@ struct RvContext {
   int *d_clen = nullptr, *pin_clen = nullptr;
 
   int opt_taps = 0, opt_graph = 1, opt_profile = 0;
+  int opt_ptaps = 0, lptaps = 0;            // persist_taps: per-step logits of the persistent decode (debug)
   std::map<std::string, ProfEntry> prof;
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -308,7 +309,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if (!S_out || (B > 0 && L > 1 && !calls && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
   if (calls && (!calls->lut || !calls->bases || !calls->lengths || !calls->probs)) return fail(h, RV_EINVAL, "null calls output pointer");
   HIPCHK(h, hipSetDevice(c.device));
-  h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps;
+  h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps; h->lptaps = h->opt_ptaps;
   *S_out = 0;
   if (B == 0 || L <= 1) return RV_OK;
 
@@ -395,7 +396,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     d.step_align = h->step_align;
   } else {
     d.step_align = nullptr;
-    if (!greedy) d.step_logits = nullptr;
+    if (!greedy && !h->opt_ptaps) d.step_logits = nullptr;
   }
 
   // The slab decodes as `nsplit` independent sub-slabs on concurrent streams (inside one hipGraph):
@@ -567,8 +568,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
 #define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(h, RV_EHIP, "%s: %s", #x, hipGetErrorString(e_)); return bail(RV_EHIP); } } while (0)
   HIPTRY(hipSetDevice(c.device));
   HIPTRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  configure_decode_kernels();
-  configure_rec_kernels();
+  HIPTRY(configure_decode_kernels());    // a refused LDS opt-in would otherwise surface as an opaque launch error later
+  HIPTRY(configure_rec_kernels());
   const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
   const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
   const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
@@ -765,6 +766,7 @@ int rv_greedy_search_dev(rv_handle h, const float* raw, const float* event, int3
 int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!h || !key) return RV_EINVAL;
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
+  else if (!strcmp(key, "persist_taps")) h->opt_ptaps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
   else if (!strcmp(key, "persistent_decode")) h->opt_persist = value != 0;
@@ -802,11 +804,15 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
   }
   else if ((!strncmp(name, "step_", 5) || !strcmp(name, "parent_ids")) && h->lsplit > 1)
     return fail(h, RV_ESTATE, "per-step records are laid out per sub-slab when decode_split > 1; read them with decode_split=1 or debug_taps=1");
+  else if (!strcmp(name, "chunk_steps")) {
+    if (!h->lpersist) return fail(h, RV_ESTATE, "chunk_steps exist only after a persistent decode");
+    src = h->d_chunk_steps; n = B; kind = 1;
+  }
   else if (!strcmp(name, "step_ids")) { src = d.step_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "parent_ids")) { src = d.parent_ids; n = S * B * W; kind = 1; }
   else if (!strcmp(name, "step_scores")) { src = d.step_scores; n = S * B * W; }
   else if (!strcmp(name, "step_logits")) {
-    if (!h->ltaps && !h->lgreedy) return fail(h, RV_ESTATE, "step_logits needs option debug_taps=1");
+    if (!h->ltaps && !h->lgreedy && !h->lptaps) return fail(h, RV_ESTATE, "step_logits needs option debug_taps=1 or persist_taps=1");
     src = d.step_logits; n = S * B * W * V;
   } else if (!strcmp(name, "step_alignments")) {
     if (!h->ltaps) return fail(h, RV_ESTATE, "step_alignments needs option debug_taps=1");

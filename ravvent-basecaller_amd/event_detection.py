@@ -33,7 +33,7 @@ class EventDetector:
         """-> (start i64[n], length i64[n], mean f64[n], stdv f64[n])"""
         lib = _capi.load_library()
         x = np.ascontiguousarray(np.asarray(raw), np.float64).ravel()
-        cap = x.size // max(1, self.params["window_length1"] // 2 + 1) + 8    # events are > w1/2 samples apart
+        cap = x.size + 8    # an event is at least one sample long: this capacity can never be exceeded
         st = np.empty(cap, np.int64); ln = np.empty(cap, np.int64)
         mu = np.empty(cap, np.float64); sd = np.empty(cap, np.float64)
         n = ctypes.c_size_t(0)

@@ -100,6 +100,38 @@ def test_beam_search_matches_oracle(rv, oracle, W):
     bc.close()
 
 
+@pytest.mark.parametrize("W,dec_depth", [(1, 1), (5, 1), (8, 1), (3, 2)])
+def test_persistent_decode_step_logits(rv, oracle, W, dec_depth):
+    """Tensor-level check of the DEFAULT product path in beam mode: the one-launch persistent decode records its
+    per-step logits (option persist_taps); logits <= 1e-4, ids / parents identical to the fp64 oracle, for every
+    step a chunk ran (a chunk stops recording at its own last step, `chunk_steps`)."""
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, decoder_depth=dec_depth, max_batch=16)
+    flat = rv.weights.init_weights(bc.cfg, seed=13)
+    flat["b_fc"][bc.cfg.end_token] = 0.5          # chunks stop at different steps
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    B, L = 9, 18
+    raw, ev, _ = rv.synthetic.make_slab(B, 70, 14, seed=40 + W)
+    bc.set_option("persist_taps", 1)
+    bc.set_option("profile", 1)
+    tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+    assert "dec_persist" in bc.profile()                     # the persistent kernel ran, not the per-step path
+    taps = {}
+    otok, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
+    S = otok.shape[1]
+    assert tok.shape == otok.shape and (tok.numpy() == otok).all() and np.abs(sc.numpy() - osc).max() < TOL
+    cs = bc.get_tensor("chunk_steps").astype(int)
+    assert cs.max() == S and (cs >= 1).all()
+    lg = bc.get_tensor("step_logits").reshape(S, B, W, 7)
+    ids = bc.get_tensor("step_ids").reshape(S, B, W)
+    par = bc.get_tensor("parent_ids").reshape(S, B, W)
+    for b in range(B):
+        n = cs[b]
+        assert np.abs(lg[:n, b] - taps["step_logits"][:n, b]).max() < TOL, b
+        assert (ids[:n, b] == taps["step_ids"][:n, b]).all() and (par[:n, b] == taps["parent_ids"][:n, b]).all(), b
+    bc.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # committed golden fixtures (tests/golden, regenerated by make_golden.py from exact seeds)
 import importlib.util
@@ -253,7 +285,7 @@ def test_every_documented_option_is_accepted(rv):
     doc = hdr[hdr.index("/* Options:"):hdr.index("int rv_set_option")]
     keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
     assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
-            "fused_projection", "persistent_decode", "profile"} <= keys
+            "fused_projection", "persistent_decode", "persist_taps", "profile"} <= keys
     bc, _ = _mk(rv)
     for k in sorted(keys):
         bc.set_option(k, 1 if k != "attend_threads" else 256)
