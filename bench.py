@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Ravvent hot path (Basecaller.beam_search_prediction) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--strong]
 
-A "step" is one pass of the hot path over one slab of synthetic chunks per GPU: workload C3 of
-BASELINE.json (joint raw+event mode, 300-sample raw windows + 30 events, beam 5, 256 chunks,
-max_output_len 48), inputs resident in HBM before the timed region, outputs left in HBM; with
-N>1 every rank decodes its own slab (weak scaling, chunks shard embarrassingly) and one RCCL
-all-gather of the [B,L-1] tokens+scores closes each step.  Rank 0 prints ONE JSON line.
+With N > 1 and no launcher in the environment this script starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...` as a CHILD process (before
+anything here touches the GPU), relays its JSON line and exits with its code; started under a launcher
+(WORLD_SIZE set) it is one rank of that job.
 
-metric: kbases/s = chunks/s * 6 bases per chunk / 1000 (stride 6 events => ~6 new bases per chunk,
-/root/reference/ravvent_performance_evaluator.py:16); chunks/s is reported beside it.
+A "step" is one pass of the hot path over one batch of synthetic chunks: workload C3 of BASELINE.json (joint
+raw+event mode, 300-sample raw windows + 30 events, beam 5, max_output_len 48), inputs resident in HBM before the
+timed region, outputs left in HBM.
+  weak scaling (default): 256 chunks per GPU per step; with N > 1 the global slab of N x 256 chunks goes through the
+    shipped multi-GPU path `dist.sharded_beam_search` (contiguous chunk shards, ONE RCCL all-gather per step).
+  --strong: a fixed read of --read-chunks (8,192) chunks per step, sharded N ways, every rank decoding its shard
+    in slabs of 256 -- what BASELINE configs 4/5 describe; same single gather.
+Rank 0 prints ONE JSON line.
+
+metric: kbases/s = chunks/s * 6 bases per chunk / 1000 (NOMINAL: stride 6 events => ~6 new bases per chunk,
+/root/reference/ravvent_performance_evaluator.py:16); chunks/s is reported beside it, and
+`read_level` holds merged bases / total_processing of the evaluator call sequence (:86,125) on base-emitting weights.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,12 +35,16 @@ if ROOT not in sys.path:
 BASES_PER_CHUNK = 6
 PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+DEC_FLOPS = lambda Tm: 369408 + 768 * Tm     # per beam row per decode step
 
 
-def algorithmic_flops(kernel, B, T_r, T_e, W, S):
-    """Algorithmic FLOPs of ONE launch of `kernel` (2 per MAC, pointwise ignored)."""
+def algorithmic_flops(kernel, B, T_r, T_e, W, S, chunk_steps=None):
+    """Algorithmic FLOPs of ONE launch of `kernel` (2 per MAC, pointwise ignored).  The decode is credited
+    B*W*S row-steps like the reference's slab-wide loop; `chunk_steps` (steps every chunk really ran in the persistent
+    decode, which leaves a chunk once its beams are finished) gives the executed count instead."""
     Tm = T_r + T_e
     rec = 2 * 128 * 512 * 2            # recurrent product, both directions, per chunk-step
+    rows = B * S if chunk_steps is None else int(sum(chunk_steps))
     return {
         "lstm_rec_raw_l0": B * T_r * (rec + 2 * 1 * 512 * 2),
         "lstm_rec_event_l0": B * T_e * (rec + 2 * 5 * 512 * 2),
@@ -41,8 +54,8 @@ def algorithmic_flops(kernel, B, T_r, T_e, W, S):
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
         "gemm_memory": B * Tm * 256 * 256 * 2,               # [keys | attention-layer image of the values] for the persistent decode
-        "decode_graph": B * W * S * (369408 + 768 * Tm),
-        "dec_persist": B * W * S * (369408 + 768 * Tm),      # the whole decode loop is one launch
+        "decode_graph": W * rows * DEC_FLOPS(Tm),
+        "dec_persist": W * rows * DEC_FLOPS(Tm),              # the whole decode loop is one launch
         "dec_cell": B * W * 2 * 256 * 512,
     }.get(kernel)
 
@@ -56,11 +69,12 @@ def algorithmic_bytes(kernel, B, T_r, T_e, W, S):
     }.get(kernel)
 
 
-def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=0, target_s=12.0):
-    """The C restatement of the oracle (oracle/ravvent_cpu.c, 'port') timed on this host's cores
-    on a bounded sample of the same workload: a 256-chunk probe sizes the sample to ~target_s
-    seconds of CPU work (sample_chunks > 0 fixes it instead)."""
-    from oracle import cpu_port                       # checker / baseline only
+def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=0, target_s=12.0, eager_s=6.0):
+    """The C restatement of the oracle (oracle/ravvent_cpu.c, 'port') timed on this host's cores on a bounded sample of
+    the same workload: a 256-chunk probe sizes the sample to ~target_s seconds of CPU work (sample_chunks > 0 fixes it
+    instead).  Beside it, as a sanity band, a torch-CPU eager engine at TF-eager op granularity."""
+    from oracle import cpu_port, torch_eager          # checker / baseline only
+    import torch
     blob = rv.weights.pack(cfg, flat)
     cores = cpu_port.max_threads()
     run = lambda r, e: cpu_port.run(cfg.oracle_cfg(), cfg.enc_depth, cfg.vocab, blob, r, e, W, L)
@@ -72,10 +86,93 @@ def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=0, target_s=12.0):
     t0 = time.perf_counter()
     tok, _ = run(raw, ev)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
-            "chunks_per_s": round(n / dt, 2), "cores": cores, "kind": "port",
-            "sample": f"{n} chunks of the same workload (joint {T_r}+{T_e}, beam {W}, L {L}) in slabs of the "
-                      f"C port's choosing, {dt:.1f} s wall on {cores} threads, S={tok.shape[1]}"}
+    out = {"value": round(n / dt * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
+           "chunks_per_s": round(n / dt, 2), "cores": cores, "kind": "port",
+           "sample": f"{n} chunks of the same workload (joint {T_r}+{T_e}, beam {W}, L {L}) in slabs of the "
+                     f"C port's choosing, {dt:.1f} s wall on {cores} threads, S={tok.shape[1]}"}
+    try:   # torch eager band: slabs of 256 like the GPU run, torch's own intra-op threads
+        w = rv.weights.flat_to_nested(cfg, flat)
+        raw, ev, _ = rv.synthetic.make_slab(256, T_r, T_e, seed=102)
+        torch_eager.beam_search(w, cfg.oracle_cfg(), raw[:8], ev[:8], W, 4)     # warm-up
+        t0 = time.perf_counter(); k = 0
+        while True:
+            torch_eager.beam_search(w, cfg.oracle_cfg(), raw, ev, W, L); k += 1
+            if time.perf_counter() - t0 > eager_s or k >= 8:
+                break
+        de = time.perf_counter() - t0
+        out["torch_eager_band"] = {"value": round(256 * k / de * BASES_PER_CHUNK / 1000.0, 4), "unit": "kbases/s",
+                                   "chunks_per_s": round(256 * k / de, 2), "cores": torch.get_num_threads(),
+                                   "sample": f"{k} slab(s) of 256 chunks, {de:.1f} s wall, torch {torch.__version__} CPU eager, "
+                                             f"one op per TF-eager op (oracle/torch_eager.py)"}
+    except Exception as e:  # the band is a sanity figure: never lose the bench line over it
+        out["torch_eager_band"] = {"error": repr(e)}
+    return out
+
+
+def read_level(rv, device, n_chunks=8192, slab=1024, pipelined=False):
+    """The reference's read-level metric (ravvent_performance_evaluator.py:86,125): bases / (t_predicting +
+    t_postprocessing + t_merge) through the evaluator call sequence, on the evaluator's own slab shape R (1024 chunks of
+    200 samples + 30 events, L 32), fused on-device post-processing + C++ merger, weights biased so that every chunk
+    emits ~31 bases (random Keras-default weights call the empty string).  Host buffers in, merged read out."""
+    T_r, T_e, L = 200, 30, 32
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=slab, max_raw_len=T_r, max_event_len=T_e,
+                       max_output_len=L, device=device)
+    flat = rv.weights.init_weights(bc.cfg, seed=22)
+    flat["b_fc"][3:7] += 1.5; flat["b_fc"][bc.cfg.end_token] -= 3.0
+    bc.set_weights_flat(flat)
+    raw, ev, nuc = rv.synthetic.make_slab(n_chunks, T_r, T_e, seed=0, L=L)
+    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=not pipelined, pipelined_merge=pipelined)
+    e.run_slabs(raw[:slab], ev[:slab], nuc[:slab], chunk_size=slab)          # warm-up
+    best = None
+    for _ in range(3):
+        r = e.run_slabs(raw, ev, nuc, chunk_size=slab)
+        if best is None or r["total_processing"] < best["total_processing"]:
+            best = r
+    bc.close()
+    tp = best["total_processing"]
+    merged = len(best["merged_seq"])
+    return {"workload": f"R: joint 200+30, beam 5, L 32, {n_chunks} chunks in slabs of {slab}, base-emitting weights, "
+                        f"fused post-processing + C++ merger" + (" pipelined behind the GPU" if pipelined else ""),
+            "chunks_per_s": round(n_chunks / tp, 1), "kbases_per_s": round(merged / tp / 1000.0, 2), "merged_bases": merged,
+            "t_predicting": round(best["t_predicting"], 5), "t_postprocessing": round(best["t_postprocessing"], 5),
+            "t_merge": round(best["t_merge"], 5), "total_processing": round(tp, 5)}
+
+
+def bahdanau_timing(rv, device, B, T_r, T_e, W, L, steps=10):
+    """north_star names Bahdanau attention (Decoder(attention_type='bahdanau'), basecaller.py:131-132): same workload,
+    per-step decode kernels in a hipGraph (the persistent decode is Luong only)."""
+    import torch
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, attention_type="bahdanau", honor_attention_type=True,
+                       max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L, device=device)
+    bc.init_random_weights(seed=22)
+    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=0)
+    x = (torch.from_numpy(raw).to(bc.device), torch.from_numpy(ev).to(bc.device))
+    bc.reuse_output_buffers = True
+    for _ in range(3):
+        tok, _ = bc.beam_search_prediction(x, W, L)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tok, _ = bc.beam_search_prediction(x, W, L)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    bc.close()
+    return {"workload": f"C3 shape, Bahdanau attention, per-step decode kernels in a hipGraph", "ms_per_step": round(dt * 1e3, 4),
+            "chunks_per_s": round(B / dt, 1), "decode_steps": int(tok.shape[1])}
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: run the job as a child `torch.distributed.run` (never an exec: this process may
+    not replace itself once anything has touched the GPU, and a child keeps that rule trivially true)."""
+    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    return p.returncode
 
 
 def main():
@@ -83,12 +180,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step (C3: 256)")
+    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per slab (C3: 256)")
     ap.add_argument("--raw-len", type=int, default=300)
     ap.add_argument("--event-len", type=int, default=30)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
+    ap.add_argument("--strong", action="store_true", help="strong scaling: a fixed read of --read-chunks chunks per step, sharded over the GPUs")
+    ap.add_argument("--read-chunks", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the read_level and bahdanau sub-lines (N=1 only)")
     ap.add_argument("--per-step-decode", action="store_true",
                     help="A/B: per-step decode kernels in a hipGraph instead of the one-launch persistent decode")
     ap.add_argument("--attend-threads", type=int, default=0, help="0 auto | 256 | 512 (library option attend_threads)")
@@ -96,6 +196,9 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-kernel event pass over the decode loop")
     ap.add_argument("--cpu-sample", type=int, default=0, help="chunks for the CPU baseline (0 = size to ~12 s)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -106,7 +209,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dist_backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -123,29 +226,24 @@ def main():
                        beam_width=W, device=local, max_batch=B, max_raw_len=T_r, max_event_len=T_e,
                        max_output_len=L)
     flat = bc.init_random_weights(seed=22)            # Keras-default initialisers, seed as ravvent.py:9
+    bc.reuse_output_buffers = True                    # explicit opt-in: no allocator traffic in the timed loop
     if args.attend_threads:
         bc.set_option("attend_threads", args.attend_threads)
     if args.per_step_decode:
         bc.set_option("persistent_decode", 0)
-    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=rank)
+    # the global batch of a step: every rank holds all of it (inputs are ~2 KB per chunk) and decodes its contiguous shard
+    n_global = args.read_chunks if args.strong else world * B
+    raw, ev, _ = rv.synthetic.make_slab(n_global, T_r, T_e, seed=0)
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
-    packed = gathered = None
-    if world > 1:   # tokens (i32) and scores (f32 bits) travel in ONE fixed-shape all-gather per step
-        packed = torch.zeros((B, 2 * (L - 1)), dtype=torch.int32, device=dev)
-        gathered = torch.empty((world * B, 2 * (L - 1)), dtype=torch.int32, device=dev)
+    lo, hi = rv.dist.shard_range(n_global, rank, world)
 
     def step():
-        tok, sc = bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
-        if world > 1:   # the path's single exchange: gather every rank's calls (RCCL over xGMI)
-            S = tok.shape[1]
-            packed[:, :S] = tok
-            packed[:, L - 1:L - 1 + S] = sc.view(torch.int32)
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(gathered, packed)
-            else:
-                g_cpu = torch.empty(gathered.shape, dtype=gathered.dtype)
-                dist.all_gather_into_tensor(g_cpu, packed.cpu())
-        return tok, sc
+        if world > 1:   # the shipped multi-GPU path: shard -> decode -> ONE all-gather (RCCL over xGMI)
+            return rv.dist.sharded_beam_search(bc, d_raw, d_ev, W, L, slab=B)
+        out = None
+        for a in range(0, n_global, B):
+            out = bc.beam_search_prediction((d_raw[a:a + B], d_ev[a:a + B]), beam_width=W, max_output_len=L)
+        return out
 
     def fence():
         if world > 1:
@@ -170,26 +268,34 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
-    S = int(tok.shape[1])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof_dec = bc.profile()            # decode launch(es), measured inside the timed region
     prof = dict(prof_dec)
+    slabs_per_step = -(-(hi - lo) // B)            # this rank's launches of each kernel per step
+    x0 = (d_raw[lo:lo + B], d_ev[lo:lo + B])       # this rank's first slab: what the untimed per-kernel passes run on
+    Bk = int(x0[0].shape[0])
+    chunk_steps = None
     if rank == 0:                      # every launch, in a short untimed pass (local decode only: no collective here)
-        n_pass = min(args.steps, 10)
+        n_pass = min(args.steps * slabs_per_step, 10)
         bc.set_option("profile", 1)
         bc.reset_profile()
         for _ in range(n_pass):
-            bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
-        prof = {k: (v[0] * args.steps / n_pass, v[1] * args.steps / n_pass) for k, v in bc.profile().items()}   # scaled to args.steps
+            tk0, _ = bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
+        scale = args.steps * slabs_per_step / n_pass
+        prof = {k: (v[0] * scale, v[1] * scale) for k, v in bc.profile().items()}   # scaled to the timed region's launch count
         prof.update(prof_dec)
+        S = int(tk0.shape[1])
+        if not args.per_step_decode:
+            chunk_steps = bc.get_tensor("chunk_steps").astype(int)
     if os.environ.get("RV_BENCH_VERBOSE"):
         print("per-step ms:", " ".join(f"{x*1e3:.2f}" for x in per_step), file=sys.stderr)
 
     if rank == 0:
-        chunks_per_s = world * B * args.steps / dt
+        chunks_per_s = n_global * args.steps / dt
+        launches = args.steps * slabs_per_step
         # Per-kernel view of the decode graph: a short extra pass with hipEvents around EVERY kernel
         # (option profile=2: the graph is bypassed, same kernels, same stream).  Not part of `value`.
         dec = {}
@@ -197,11 +303,11 @@ def main():
             bc.set_option("profile", 2)
             bc.reset_profile()
             for _ in range(3):     # local decode only: no collective here (this block runs on rank 0 alone)
-                bc.beam_search_prediction((d_raw, d_ev), beam_width=W, max_output_len=L)
+                bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
             dec = {k: v for k, v in bc.profile().items() if k.startswith("dec_") and k != "dec_finalize"}
             bc.set_option("profile", 1)
         # time per slab of every kernel name (graph replaced by its members when available)
-        per_slab = {k: v[0] / args.steps for k, v in prof.items()}
+        per_slab = {k: v[0] / launches for k, v in prof.items()}
         if dec:
             per_slab.pop("decode_graph", None)
             for k, (ms, n) in dec.items():
@@ -210,53 +316,75 @@ def main():
         # the decode launch is timed inside the timed region (profile 3); other kernels come from the untimed passes
         ms, n = prof_dec[name] if name in prof_dec else (dec[name] if name in dec else prof[name])
         avg_ms = ms / max(n, 1)
-        by = algorithmic_bytes(name, B, T_r, T_e, W, S)
+        by = algorithmic_bytes(name, Bk, T_r, T_e, W, S)
         if by:
             achieved = by / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": n,
                     "bytes_per_launch": by, "traffic": None}
         else:
-            fl = algorithmic_flops(name, B, T_r, T_e, W, S)
+            fl_ref = algorithmic_flops(name, Bk, T_r, T_e, W, S)
+            fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, chunk_steps) if fl_ref else None
             achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
                     "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
-                    "avg_launch_ms": round(avg_ms, 5), "launches": n, "flops_per_launch": fl, "traffic": None}
+                    "avg_launch_ms": round(avg_ms, 5), "launches": n, "flops_per_launch": fl,
+                    "flops_reference": fl_ref, "flops_executed": fl, "traffic": None}
         roof["share_of_slab_time"] = round(per_slab[name] / sum(per_slab.values()), 3)
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 for k, v in json.load(f).items():
-                    if k.split("@")[0] == name and B == 256:          # collected on this workload only
+                    if k.split("@")[0] == name and Bk == 256:          # collected on this workload only
                         roof["traffic"] = v["hbm_bytes_per_launch"]
-        # whole-path view: algorithmic FLOPs of the path / step time vs the fp32 peak
-        path_fl = B * (T_r * 1050624 + T_e * 1058816 + (T_r + T_e) * 65536 + W * S * (369408 + 768 * (T_r + T_e)))
-        path_tf = world * path_fl / (dt / args.steps) / 1e12
+        # whole-path view: algorithmic FLOPs of the path / step time vs the fp32 peak.  `flops_reference`
+        # credits the decode with B*W*S row-steps (the reference's slab-wide loop); `flops_executed` with the chunk-steps
+        # the persistent decode really ran on this rank's first slab (a chunk leaves the loop once its beams are finished).
+        enc_fl = T_r * 1050624 + T_e * 1058816 + (T_r + T_e) * 65536
+        path_ref = enc_fl + W * S * DEC_FLOPS(T_r + T_e)
+        exec_steps = float(np.mean(chunk_steps)) if chunk_steps is not None else float(S)
+        path_exec = enc_fl + W * exec_steps * DEC_FLOPS(T_r + T_e)
+        tf_ref = n_global * path_ref / (dt / args.steps) / 1e12
+        tf_exec = n_global * path_exec / (dt / args.steps) / 1e12
         total_ms = sum(v[0] for v in prof.values())
+        mode = "strong" if args.strong else "weak"
         out = {
             "metric": "kbases/s, raw+event joint mode, beam=5 (hot path: beam_search_prediction)",
             "value": round(chunks_per_s * BASES_PER_CHUNK / 1000.0, 3), "unit": "kbases/s",
+            "value_note": "nominal: chunks/s x 6 bases per chunk (stride 6); random-init weights call mostly empty strings -- see read_level",
             "chunks_per_s": round(chunks_per_s, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": mode,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: joint raw+event, T_raw={T_r}, T_event={T_e}, beam={W}, "
-                                   f"{B} chunks/GPU/step, max_output_len={L}, enc_depth=2, dec_depth=1, units=128, luong",
-                       "decode_steps": S, "weights": "random-init (Keras defaults, seed 22)",
-                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step" if world > 1 else "")},
+                                   + (f"{B} chunks/GPU/step" if not args.strong else f"one read of {n_global} chunks/step in slabs of {B}")
+                                   + f", max_output_len={L}, enc_depth=2, dec_depth=1, units=128, luong",
+                       "decode_steps": S, "decode_steps_executed_mean": round(exec_steps, 2),
+                       "weights": "random-init (Keras defaults, seed 22)",
+                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step (dist.sharded_beam_search)" if world > 1 else "")},
             "roofline": roof,
-            "roofline_path": {"bound": "mfma", "achieved": round(path_tf, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
-                              "frac": round(path_tf / (PEAK_F32_TFLOPS * world), 4), "flops_per_chunk": path_fl // B},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+            "roofline_path": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
+                              "frac": round(tf_exec / (PEAK_F32_TFLOPS * world), 4),
+                              "flops_per_chunk_reference": path_ref, "flops_per_chunk_executed": round(path_exec),
+                              "achieved_reference": round(tf_ref, 2), "frac_reference": round(tf_ref / (PEAK_F32_TFLOPS * world), 4)},
+            "kernel_ms_per_slab": {k: round(v, 4) for k, v in sorted(per_slab.items())},
             "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
             "device_ms_per_step": round(total_ms / args.steps, 4),
             "step_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
         }
+    bc.close()
+    if rank == 0:
+        if world == 1 and not args.no_extras:      # sub-lines outside the timed region (own handles)
+            try:
+                out["read_level"] = read_level(rv, local)
+                out["read_level_pipelined"] = read_level(rv, local, pipelined=True)
+                out["bahdanau"] = bahdanau_timing(rv, local, B, T_r, T_e, W, L)
+            except Exception as e:
+                out["extras_error"] = repr(e)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rv, bc.cfg, flat, T_r, T_e, W, L, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    bc.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -209,13 +209,18 @@ class Basecaller:
         return tokens[:, :S.value], logits[:, :S.value]
 
     def _out_buffers(self, kind, B, steps, V):
-        """Device output buffers are reused per shape (no allocator traffic in the hot loop); the
-        returned tensors are fresh views, valid until the next call with the same shape."""
+        """Device outputs of the `*_dev` entry points.  Default: FRESH tensors per call, like the reference's return
+        values (callers may keep one result per slab in a list); torch's caching allocator makes that cheap.
+        `reuse_output_buffers = True` (explicit opt-in, bench.py's timed loop) returns views into one buffer per shape,
+        valid only until the next call with that shape."""
+        shape2 = (B, steps, V) if kind == "greedy" else (B, steps)
+        if not getattr(self, "reuse_output_buffers", False):
+            return (torch.empty((B, steps), dtype=torch.int32, device=self.device),
+                    torch.empty(shape2, dtype=torch.float32, device=self.device))
         key = (kind, B, steps, V)
         cache = self.__dict__.setdefault("_outs", {})
         if key not in cache:
             cache.clear()
-            shape2 = (B, steps, V) if kind == "greedy" else (B, steps)
             cache[key] = (torch.empty((B, steps), dtype=torch.int32, device=self.device),
                           torch.empty(shape2, dtype=torch.float32, device=self.device))
         return cache[key]

@@ -3,9 +3,10 @@
 One process per GPU; a read's (or a queue's) chunk range is cut into `world` contiguous, nearly
 equal pieces (contiguity keeps the order the merger needs); weights are replicated; every rank
 decodes its piece with its own `Basecaller`; ONE fixed-shape all-gather (RCCL over xGMI on
-MI355X, gloo on CPU in the tests) of `[n_max, L-1]` tokens + scores ends the call.  No collective
-touches the data path before that.  The reference has no distributed code at all
-(SURVEY.md 2.1); this module is new, not a port.
+MI355X, gloo on CPU in the tests) ends the call: tokens, score bits and the shard's step count
+travel in a single int32 tensor `[n_max, 2 (L-1) + 1]`.  No collective touches the data path
+before that.  The reference has no distributed code at all; this module is new,
+not a port.
 """
 from __future__ import annotations
 
@@ -20,52 +21,158 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _collective_device(like: torch.Tensor, group=None, device=None) -> torch.device:
+    """Where the gather buffers live: RCCL moves device memory only, gloo host memory."""
+    if device is not None:
+        return torch.device(device)
+    if dist.get_backend(group) == "nccl":
+        return like.device if like.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _read_order_index(n_total: int, world: int, n_max: int, dev) -> torch.Tensor:
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(torch.arange(r * n_max, r * n_max + (hi - lo), device=dev))
+    return torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long, device=dev)
+
+
+_BUFFERS: dict = {}
+
+
+def _buffers(kind, rows, cols, world, dev):
+    key = (kind, rows, cols, world, str(dev))
+    if key not in _BUFFERS:
+        if len(_BUFFERS) > 16:
+            _BUFFERS.clear()
+        _BUFFERS[key] = (torch.empty((rows, cols), dtype=torch.int32, device=dev),
+                         torch.empty((world * rows, cols), dtype=torch.int32, device=dev))
+    return _BUFFERS[key]
+
+
 def gather_calls(tokens: torch.Tensor, scores: torch.Tensor, steps: int, n_total: int, max_steps: int,
-                 end_token: int = 1, group=None):
-    """All-gather per-rank results into read order.
+                 end_token: int = 1, group=None, device=None):
+    """All-gather per-rank results into read order with ONE collective.
 
     tokens/scores: this rank's [n_local, S_local] (S_local <= max_steps); returns
     (tokens [n_total, S], scores [n_total, S]) with S = max over ranks of S_local.  The reference
     loop runs until EVERY row of the slab is finished, so a rank whose shard
     finished earlier is extended with exactly what that loop would have emitted for its rows had
     it run on: all beams finished => the end token, at an unchanged top-1 score.  The gathered
-    result is therefore identical to the single-GPU result for the whole slab."""
+    result is therefore identical to the single-GPU result for the whole slab.
+
+    Wire format, one int32 row per chunk: [tokens (L-1) | score bits (L-1) | S_local]."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = tokens.device
-    n_max = -(-n_total // world)
-    pt = torch.full((n_max, max_steps), end_token, dtype=torch.int32, device=dev)
-    ps = torch.zeros((n_max, max_steps), dtype=torch.float32, device=dev)
+    dev = _collective_device(tokens, group, device)
+    n_max = -(-n_total // world) if n_total else 0
+    cols = 2 * max_steps + 1
+    packed, gathered = _buffers("calls", max(n_max, 1), cols, world, dev)
     n_loc, s_loc = tokens.shape
-    pt[:n_loc, :s_loc] = tokens
-    ps[:n_loc, :s_loc] = scores
-    if 0 < s_loc < max_steps:
-        ps[:n_loc, s_loc:] = scores[:, s_loc - 1:s_loc]
-    gt = torch.empty((world * n_max, max_steps), dtype=torch.int32, device=dev)
-    gs = torch.empty((world * n_max, max_steps), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gt, pt, group=group)
-    dist.all_gather_into_tensor(gs, ps, group=group)
-    s = torch.tensor([steps], dtype=torch.int32, device=dev)
-    dist.all_reduce(s, op=dist.ReduceOp.MAX, group=group)
-    S = int(s.item())
-    rows = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        rows.append(torch.arange(r * n_max, r * n_max + (hi - lo), device=dev))
-    idx = torch.cat(rows)
-    return gt[idx, :S], gs[idx, :S]
+    packed[:, :max_steps] = end_token
+    packed[:, max_steps:] = 0
+    packed[:, 2 * max_steps] = int(steps)
+    if n_loc and s_loc:
+        packed[:n_loc, :s_loc] = tokens.to(dev, torch.int32)
+        sc = scores.to(dev, torch.float32).contiguous()
+        packed[:n_loc, max_steps:max_steps + s_loc] = sc.view(torch.int32)
+        if s_loc < max_steps:      # finished shard: unchanged top-1 score on the steps the slab-wide loop would still run
+            packed[:n_loc, max_steps + s_loc:2 * max_steps] = sc[:, s_loc - 1:s_loc].view(torch.int32)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    S = int(gathered[:, 2 * max_steps].max().item()) if n_total else 0
+    idx = _read_order_index(n_total, world, max(n_max, 1), dev)
+    out = gathered[idx]
+    return out[:, :S].contiguous(), out[:, max_steps:max_steps + S].contiguous().view(torch.float32)
 
 
-def sharded_beam_search(basecaller, raw, event, beam_width: int, max_output_len: int, group=None):
-    """Decode this rank's contiguous shard of the slab and gather everyone's calls.
-    raw / event: the FULL slab (host arrays or tensors); every rank holds the same inputs."""
+def _decode_shard(basecaller, raw, event, lo, hi, beam_width, max_output_len, slab):
+    """This rank's [lo, hi) in slabs of at most `slab` chunks -> ([n_local, S_local] tokens, scores, S_local); slabs that
+    stop earlier are extended like a shard that stops earlier (see gather_calls)."""
+    mode = basecaller.input_data_type
+    steps = max(int(max_output_len) - 1, 0)
+    end_token = int(basecaller.output_end_token)
+    slab = int(slab) if slab else max(hi - lo, 1)
+    parts = []
+    for a in range(lo, hi, slab):
+        b = min(a + slab, hi)
+        pick = lambda x: None if x is None else x[a:b]
+        inp = {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
+        parts.append(basecaller.beam_search_prediction(inp, beam_width=beam_width, max_output_len=max_output_len))
+    if len(parts) == 1:
+        tok, sc = parts[0]
+        return tok, sc, tok.shape[1]
+    if not parts:
+        return torch.zeros((0, 0), dtype=torch.int32), torch.zeros((0, 0)), 0
+    S = max(t.shape[1] for t, _ in parts)
+    dev = parts[0][0].device
+    tok = torch.full((hi - lo, S), end_token, dtype=torch.int32, device=dev)
+    sc = torch.zeros((hi - lo, S), dtype=torch.float32, device=dev)
+    row = 0
+    for t, s in parts:
+        n, si = t.shape
+        tok[row:row + n, :si] = t
+        sc[row:row + n, :si] = s
+        if 0 < si < S:
+            sc[row:row + n, si:] = s[:, si - 1:si]
+        row += n
+    assert S <= steps
+    return tok, sc, S
+
+
+def sharded_beam_search(basecaller, raw, event, beam_width: int, max_output_len: int, group=None, slab: int | None = None):
+    """Decode this rank's contiguous shard of the slab and gather everyone's calls (one collective).
+    raw / event: the FULL slab (host arrays or tensors, host or device); every rank holds the same inputs.
+    `slab`: decode the shard in pieces of at most that many chunks (a shard larger than the handle's max_batch)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = (raw if raw is not None else event).shape[0]
     lo, hi = shard_range(n, rank, world)
-    pick = lambda x: None if x is None else x[lo:hi]
-    mode = basecaller.input_data_type
-    inp = {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
-    tok, sc = basecaller.beam_search_prediction(inp, beam_width=beam_width, max_output_len=max_output_len)
-    return gather_calls(tok, sc, tok.shape[1], n, max(int(max_output_len) - 1, 0),
-                        end_token=int(basecaller.output_end_token), group=group)
+    tok, sc, S = _decode_shard(basecaller, raw, event, lo, hi, beam_width, max_output_len, slab)
+    dev = getattr(basecaller, "device", None) if dist.get_backend(group) == "nccl" else None
+    return gather_calls(tok, sc, S, n, max(int(max_output_len) - 1, 0),
+                        end_token=int(basecaller.output_end_token), group=group, device=dev)
+
+
+def pack_call_arrays(bases, probs, lens, n_total: int, max_steps: int, world: int):
+    """This rank's rows of the read-level wire format, one int32 row per chunk, padded to the common shard size
+    n_max = ceil(n_total / world): [prob bits (L-1) | base bytes, 4 per word | length]."""
+    import numpy as np
+    n_max = max(-(-n_total // world) if n_total else 0, 1)
+    bw = -(-max_steps // 4)
+    cols = max_steps + bw + 1
+    row = np.zeros((n_max, cols), np.int32)
+    n_loc = int(len(lens))
+    if n_loc:
+        row[:n_loc, :max_steps] = np.ascontiguousarray(probs, np.float32).view(np.int32)
+        bb = np.zeros((n_loc, 4 * bw), np.uint8)
+        bb[:, :max_steps] = bases
+        row[:n_loc, max_steps:max_steps + bw] = bb.view(np.int32)
+        row[:n_loc, cols - 1] = lens
+    return row
+
+
+def unpack_call_arrays(gathered, n_total: int, max_steps: int, world: int):
+    """[world * n_max, cols] gathered rows (rank-major, as all_gather_into_tensor lays them out) -> read order:
+    (bases u8 [n_total, L-1], probs f32 [n_total, L-1], lens i32 [n_total])."""
+    import numpy as np
+    n_max = max(-(-n_total // world) if n_total else 0, 1)
+    bw = -(-max_steps // 4)
+    cols = max_steps + bw + 1
+    idx = _read_order_index(n_total, world, n_max, "cpu").numpy()
+    g = np.ascontiguousarray(np.asarray(gathered).reshape(world * n_max, cols)[idx])
+    out_probs = np.ascontiguousarray(g[:, :max_steps]).view(np.float32)
+    out_bases = np.ascontiguousarray(g[:, max_steps:max_steps + bw]).view(np.uint8)[:, :max_steps]
+    return np.ascontiguousarray(out_bases), out_probs, np.ascontiguousarray(g[:, cols - 1])
+
+
+def gather_call_arrays(bases, probs, lens, n_total: int, max_steps: int, group=None, device=None):
+    """Read-level form (BASELINE configs 4/5): every rank's per-chunk base letters, per-base probabilities and string
+    lengths (`Basecaller.beam_search_call_arrays`) gathered into read order with ONE collective; returns numpy arrays
+    as `merger.Merger.merge_arrays` takes them."""
+    world = dist.get_world_size(group)
+    ref = torch.zeros(0, device=device) if device is not None else torch.zeros(0)
+    dev = _collective_device(ref, group, device)
+    packed = torch.from_numpy(pack_call_arrays(bases, probs, lens, n_total, max_steps, world)).to(dev)
+    gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    return unpack_call_arrays(gathered.cpu().numpy(), n_total, max_steps, world)

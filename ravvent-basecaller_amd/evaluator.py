@@ -100,6 +100,75 @@ class PerformanceEvaluator:
             "nuc_preds": nuc_preds, "merged_seq": merged_seq,
         }
 
+    # ------------------------------------------------------------------ BASELINE configs 4/5: one read over N GPUs
+    def run_read_sharded(self, signal, labels, chunk_size: int = 1024, beam_width: int = 5, group=None):
+        """`run_read` with the read's chunks sharded over the ranks of `group` (one process per GPU): every rank cuts the
+        read into chunks (host pre-processing, outside the metric, deterministic), decodes ITS contiguous range
+        (`dist.shard_range`) in slabs of `chunk_size`, ONE all-gather returns every chunk's call in read order, and rank 0
+        stitches them with the C++ merger (ravvent_performance_evaluator.py:24-87 with :51-55 sharded and :73-75 on rank 0).
+        `merged_seq` is None on the other ranks."""
+        from . import data_loader as dl
+        ranges_ids = np.asarray(labels)[:, :2].astype(int)
+        ref_seq = "".join(list(np.asarray(labels)[:, 2]))
+        samples_num = int(ranges_ids[-1, 1] - ranges_ids[0, 0])
+        start = timer()
+        slab = dl.snippets_to_slab(*dl.prepare_snippets(signal, ranges_ids, np.asarray(labels)[:, 2], self.stride))
+        t_chunking = timer() - start
+        res = self.run_slabs_sharded(*slab, bases_num=len(ref_seq), samples_num=samples_num, chunk_size=chunk_size,
+                                     beam_width=beam_width, group=group)
+        res["t_data_loading"] += t_chunking
+        res["total"] += t_chunking
+        return res
+
+    def run_slabs_sharded(self, raw_snippets, event_snippets, nuc_tk_snippets, bases_num=None, samples_num=None,
+                          chunk_size: int = 1024, beam_width: int = 5, group=None):
+        """Body of `run_read_sharded` from the padded snippet arrays every rank holds."""
+        import torch.distributed as tdist
+        from . import dist as rdist
+        world, rank = tdist.get_world_size(group), tdist.get_rank(group)
+        n = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
+        L = int(nuc_tk_snippets.shape[1])
+        steps = max(L - 1, 0)
+        lo, hi = rdist.shard_range(n, rank, world)
+        start = timer()
+        bases, probs, lens = self.decode_range(raw_snippets, event_snippets, lo, hi, L, chunk_size, beam_width)
+        t_predicting = timer() - start
+        start = timer()
+        dev = getattr(self.basecaller, "device", None) if tdist.get_backend(group) == "nccl" else None
+        g_bases, g_probs, g_lens = rdist.gather_call_arrays(bases, probs, lens, n, steps, group=group, device=dev)
+        t_gather = timer() - start
+        start = timer()
+        merged_seq = None
+        if rank == 0:
+            merged_seq = self.merger.merge_arrays(g_bases, g_probs, g_lens)[0] if n else ""
+        t_merge = timer() - start
+        if bases_num is None:
+            bases_num = n * self.stride
+        return {
+            "bases_num": int(bases_num), "samples_num": samples_num, "chunks_num": n, "chunks_local": hi - lo,
+            "t_data_loading": 0.0, "t_predicting": t_predicting, "t_postprocessing": 0.0, "t_gather": t_gather,
+            "t_merge": t_merge, "total": t_predicting + t_gather + t_merge,
+            "total_processing": t_predicting + t_gather + t_merge,
+            "call_arrays": (g_bases, g_probs, g_lens), "merged_seq": merged_seq,
+        }
+
+    def decode_range(self, raw_snippets, event_snippets, lo: int, hi: int, max_output_len: int, chunk_size: int = 1024,
+                     beam_width: int = 5):
+        """Calls of chunks [lo, hi) in slabs of `chunk_size`: (bases u8 [hi-lo, L-1], probs f32, lens i32) -- one rank's
+        share of `run_slabs_sharded`."""
+        mode = self.basecaller.input_data_type
+        steps = max(int(max_output_len) - 1, 0)
+        bases = np.zeros((hi - lo, steps), np.uint8)
+        probs = np.zeros((hi - lo, steps), np.float32)
+        lens = np.zeros(hi - lo, np.int32)
+        for a in range(lo, hi, chunk_size):
+            b = min(a + chunk_size, hi)
+            x = {"joint": lambda: (raw_snippets[a:b], event_snippets[a:b]), "raw": lambda: raw_snippets[a:b],
+                 "event": lambda: event_snippets[a:b]}[mode]()
+            bs, pr, ln = self.basecaller.beam_search_call_arrays(x, beam_width=beam_width, max_output_len=max_output_len)
+            bases[a - lo:b - lo] = bs; probs[a - lo:b - lo] = pr; lens[a - lo:b - lo] = ln
+        return bases, probs, lens
+
     def _run_pipelined(self, data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width, t_data_loading):
         from concurrent.futures import ThreadPoolExecutor
         sm = merger.StreamingMerger(self.merger.scores_id, self.merger.overlap_seq_len)

@@ -135,3 +135,19 @@ def test_oracle_reproduces_golden(rv, oracle, name):
     assert (taps["mask"] == g["mask"]).all()
     assert np.abs(taps["enc_output"][:, ::5, ::16] - g["enc_output_sample"]).max() < 1e-6
     assert oracle.tokens_to_nuc_sequences(tok) == [str(x) for x in g["strings"]]
+
+
+@pytest.mark.parametrize("mode,attention,W,dec_depth", [("joint", "luong", 5, 1), ("raw", "bahdanau", 3, 1), ("event", "luong", 1, 2)])
+def test_torch_eager_band_matches_oracle(rv, oracle, mode, attention, W, dec_depth):
+    """bench.py's second CPU engine (oracle/torch_eager.py, TF-eager-like op granularity) computes the same calls as
+    the numpy oracle: tokens identical, scores within fp32 rounding."""
+    from oracle import torch_eager
+    cfg = rv.RvConfig(mode=mode, attention=attention, dec_depth=dec_depth)
+    flat = rv.weights.init_weights(cfg, seed=6)
+    flat["b_fc"][cfg.end_token] = 0.7           # early finishes: finished-beam masking and gather_tree padding
+    w = rv.weights.flat_to_nested(cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(5, 40, 12, seed=2)
+    tok, sc = torch_eager.beam_search(w, cfg.oracle_cfg(), raw, ev, W, 14)
+    otok, osc = oracle.beam_search(w, cfg.oracle_cfg(), raw, ev, W, 14, dtype=np.float32)
+    assert tok.shape == otok.shape and (tok == otok).all()
+    assert np.abs(sc - osc).max() < 1e-4

@@ -507,3 +507,123 @@ def test_fused_postprocessing_matches_host_form(rv):
     ev0 = rv.evaluator.PerformanceEvaluator(bc).run_slabs(raw, ev, np.zeros((40, 24), np.int64), chunk_size=64)
     assert [a for a, _ in ev1["nuc_preds"]] == [a for a, _ in ev0["nuc_preds"]]
     bc.close()
+
+
+def test_device_outputs_are_fresh_per_call(rv):
+    """Device-input calls return fresh tensors like the reference (an evaluator may keep one result per slab in a list);
+    buffer reuse is an explicit opt-in."""
+    import torch
+    bc, _ = _mk(rv)
+    raw, ev, _ = rv.synthetic.make_slab(8, 64, 12, seed=2)
+    raw2, ev2, _ = rv.synthetic.make_slab(8, 64, 12, seed=3)
+    d = lambda a: torch.from_numpy(a).cuda()
+    t1, s1 = bc.beam_search_prediction((d(raw), d(ev)), 5, 12)
+    keep_t, keep_s = t1.cpu().numpy().copy(), s1.cpu().numpy().copy()
+    t2, s2 = bc.beam_search_prediction((d(raw2), d(ev2)), 5, 12)
+    assert (t1.cpu().numpy() == keep_t).all() and np.array_equal(s1.cpu().numpy(), keep_s)
+    assert not np.array_equal(s2.cpu().numpy(), keep_s)
+    g1, l1 = bc.greedy_search_prediction((d(raw), d(ev)), 12)
+    keep_l = l1.cpu().numpy().copy()
+    bc.greedy_search_prediction((d(raw2), d(ev2)), 12)
+    assert np.array_equal(l1.cpu().numpy(), keep_l)
+    bc.reuse_output_buffers = True                      # opt-in: views into one buffer per shape
+    t3, _ = bc.beam_search_prediction((d(raw), d(ev)), 5, 12)
+    t4, _ = bc.beam_search_prediction((d(raw2), d(ev2)), 5, 12)
+    assert t3.data_ptr() == t4.data_ptr()
+    bc.close()
+
+
+def _emitting(rv, bc, seed=22):
+    flat = rv.weights.init_weights(bc.cfg, seed=seed)
+    flat["b_fc"][3:7] += 1.5
+    flat["b_fc"][bc.cfg.end_token] -= 1.0
+    bc.set_weights_flat(flat)
+    return flat
+
+
+def test_sharded_read_two_shards_in_one_process(rv):
+    """BASELINE configs 4/5 on the one GPU of this box: a synthetic 8k-base read, its chunk range cut in two
+    (`dist.shard_range`), the shards decoded one after the other, packed into the all-gather wire format, laid out
+    rank-major as `all_gather_into_tensor` would, unpacked through the same read-order index and stitched by the C++
+    merger == the single-GPU evaluator on the whole read."""
+    bc, _ = _mk(rv, max_batch=256, max_raw_len=200, max_event_len=30, max_output_len=40)
+    _emitting(rv, bc)
+    sig, lab = rv.synthetic.make_read(8000, seed=11)
+    ev = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True)
+    whole = ev.run_read(sig, lab, chunk_size=256)
+    assert whole["chunks_num"] > 1000 and len(whole["merged_seq"]) > 4000
+    dl = rv.data_loader
+    lab_a = np.asarray(lab)
+    raw_s, ev_s, nuc_s = dl.snippets_to_slab(*dl.prepare_snippets(sig, lab_a[:, :2].astype(int), lab_a[:, 2], 6))
+    n, L = raw_s.shape[0], nuc_s.shape[1]
+    for world in (2, 3):
+        rows = []
+        for rank in range(world):
+            lo, hi = rv.dist.shard_range(n, rank, world)
+            b, p, l = ev.decode_range(raw_s, ev_s, lo, hi, L, chunk_size=256)
+            rows.append(rv.dist.pack_call_arrays(b, p, l, n, L - 1, world))
+        gb, gp, gl = rv.dist.unpack_call_arrays(np.concatenate(rows, axis=0), n, L - 1, world)
+        assert gb.shape == (n, L - 1) and (gl == [len(s) for s, _ in whole["nuc_preds"]]).all()
+        assert ev.merger.merge_arrays(gb, gp, gl)[0] == whole["merged_seq"]
+    bc.close()
+
+
+def _gpu_rank(rank, world, port, q):
+    import os, sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravvent_basecaller_amd as rv
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=64, max_raw_len=200, max_event_len=30,
+                       max_output_len=40, device=0)
+    flat = rv.weights.init_weights(bc.cfg, seed=22)
+    flat["b_fc"][3:7] += 1.5
+    flat["b_fc"][bc.cfg.end_token] -= 1.0
+    bc.set_weights_flat(flat)
+    raw, ev, _ = rv.synthetic.make_slab(37, 64, 12, seed=5)
+    out = {}
+    t, s = rv.dist.sharded_beam_search(bc, raw, ev, 5, 14)                                   # host inputs
+    out["host"] = (t.cpu().numpy(), s.cpu().numpy())
+    t, s = rv.dist.sharded_beam_search(bc, torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda(), 5, 14, slab=8)   # device inputs
+    out["dev"] = (t.cpu().numpy(), s.cpu().numpy())
+    t, s = rv.dist.sharded_beam_search(bc, raw[:1], ev[:1], 5, 14)                           # n < world: rank 1's shard is empty
+    out["one"] = (t.cpu().numpy(), s.cpu().numpy())
+    sig, lab = rv.synthetic.make_read(700, seed=4)
+    res = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True).run_read_sharded(sig, lab, chunk_size=64)
+    out["read"] = res["merged_seq"]
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    bc.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_on_one_gpu(rv):
+    """The shipped multi-GPU path (dist.sharded_beam_search, evaluator.run_read_sharded) with the REAL Basecaller on two
+    ranks that share this box's GPU (gloo moves the gather through host memory; RCCL refuses two ranks on one device):
+    host inputs, device inputs with slab-split shards, a shard that is empty, and a read through shard -> gather -> merge."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 2000
+    procs = [ctx.Process(target=_gpu_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bc, _ = _mk(rv, max_batch=64, max_raw_len=200, max_event_len=30, max_output_len=40)
+    _emitting(rv, bc)
+    raw, ev, _ = rv.synthetic.make_slab(37, 64, 12, seed=5)
+    t, s = bc.beam_search_prediction((raw, ev), 5, 14)
+    for key in ("host", "dev"):
+        assert out[key][0].shape == tuple(t.shape) and (out[key][0] == t.numpy()).all() and np.array_equal(out[key][1], s.numpy()), key
+    t1, s1 = bc.beam_search_prediction((raw[:1], ev[:1]), 5, 14)
+    assert (out["one"][0] == t1.numpy()).all() and np.array_equal(out["one"][1], s1.numpy())
+    sig, lab = rv.synthetic.make_read(700, seed=4)
+    single = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True).run_read(sig, lab, chunk_size=64)
+    assert len(single["merged_seq"]) > 300 and out["read"] == single["merged_seq"]
+    bc.close()
