@@ -534,7 +534,9 @@ def test_device_outputs_are_fresh_per_call(rv):
 
 
 def _emitting(rv, bc, seed=22):
-    flat = rv.weights.init_weights(bc.cfg, seed=seed)
+    """Random weights biased to call bases (gain 3: the calls vary along a read instead of one homopolymer).  Untrained
+    weights cannot call a read correctly; these tests check that the sharded and the single-GPU paths agree byte for byte."""
+    flat = rv.weights.init_weights(bc.cfg, seed=seed, gain=3.0)
     flat["b_fc"][3:7] += 1.5
     flat["b_fc"][bc.cfg.end_token] -= 1.0
     bc.set_weights_flat(flat)
@@ -551,7 +553,7 @@ def test_sharded_read_two_shards_in_one_process(rv):
     sig, lab = rv.synthetic.make_read(8000, seed=11)
     ev = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True)
     whole = ev.run_read(sig, lab, chunk_size=256)
-    assert whole["chunks_num"] > 1000 and len(whole["merged_seq"]) > 4000
+    assert whole["chunks_num"] > 1000 and len(whole["merged_seq"]) > 50
     dl = rv.data_loader
     lab_a = np.asarray(lab)
     raw_s, ev_s, nuc_s = dl.snippets_to_slab(*dl.prepare_snippets(sig, lab_a[:, :2].astype(int), lab_a[:, 2], 6))
@@ -578,7 +580,7 @@ def _gpu_rank(rank, world, port, q):
     import ravvent_basecaller_amd as rv
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=64, max_raw_len=200, max_event_len=30,
                        max_output_len=40, device=0)
-    flat = rv.weights.init_weights(bc.cfg, seed=22)
+    flat = rv.weights.init_weights(bc.cfg, seed=22, gain=3.0)
     flat["b_fc"][3:7] += 1.5
     flat["b_fc"][bc.cfg.end_token] -= 1.0
     bc.set_weights_flat(flat)
@@ -625,5 +627,5 @@ def test_sharded_two_ranks_on_one_gpu(rv):
     assert (out["one"][0] == t1.numpy()).all() and np.array_equal(out["one"][1], s1.numpy())
     sig, lab = rv.synthetic.make_read(700, seed=4)
     single = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True).run_read(sig, lab, chunk_size=64)
-    assert len(single["merged_seq"]) > 300 and out["read"] == single["merged_seq"]
+    assert len(single["merged_seq"]) > 30 and out["read"] == single["merged_seq"]
     bc.close()
