@@ -7,7 +7,7 @@ the C-ABI of include/ravvent_hip.h, with the reference's `Basecaller` class API 
 There is no CPU fallback: without the HIP library the path raises.
 """
 from .config import RvConfig  # noqa: F401
-from . import data_loader, utils, weights, synthetic, dist, evaluator, event_detection  # noqa: F401
+from . import data_loader, utils, weights, synthetic, dist, evaluator, event_detection, checkpoint  # noqa: F401
 from .basecaller import Basecaller  # noqa: F401
 
-__all__ = ["RvConfig", "Basecaller", "data_loader", "utils", "weights", "synthetic", "dist", "evaluator", "event_detection"]
+__all__ = ["RvConfig", "Basecaller", "data_loader", "utils", "weights", "synthetic", "dist", "evaluator", "event_detection", "checkpoint"]

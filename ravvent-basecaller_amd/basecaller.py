@@ -105,9 +105,14 @@ class Basecaller:
                     "rv_load_weights")
 
     def load_weights(self, path):
-        """ravvent_performance_evaluator.py:107.  Reads this build's ``.npz`` weight file
-        (weights.py); TF-format checkpoints need TensorFlow and are out of scope."""
-        self.set_weights_flat(_weights.load(str(path), self.cfg))
+        """ravvent_performance_evaluator.py:107.  `path` is either a TF-format checkpoint prefix as Keras writes it
+        (`prefix.index` + `prefix.data-*`: read by checkpoint.py without TensorFlow, variables matched by their
+        attribute paths, weights_manifest.json) or this build's own ``.npz`` weight file (weights.py)."""
+        from . import checkpoint
+        if checkpoint.is_tf_checkpoint(path):
+            self.set_weights_flat(checkpoint.flat_from_checkpoint(str(path), self.cfg))
+        else:
+            self.set_weights_flat(_weights.load(str(path), self.cfg))
         return self
 
     def init_random_weights(self, seed: int = 22, scheme: str = "keras", gain: float = 1.0):

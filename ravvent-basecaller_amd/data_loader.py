@@ -5,9 +5,10 @@ Format (T2 in SURVEY.md 8a; /root/reference/data_loader.py:12-26,110-126,230-246
 3-tuple ``(raw[B,T_r,1] f32, event[B,T_e,5] f32, nuc[B,L] i64)``, post-padded / post-truncated
 with ``INPUT_PADDING``; tokens are ``$ ... ^`` with pad id 0.  The chunker that cuts reads into
 such slabs (`prepare_snippets` / `load_data_from_single_signal_label`) is restated at the bottom:
-host-side pre-processing, a "next" row of the scope table.  Its event detector
-is pinned against the reference's own output (tests/golden/events_*.npz); the snippet cutter itself
-cannot be imported here (it sits behind `import tensorflow`) and is PARITY UNPINNED.
+host-side pre-processing, a "next" row of the scope table.  Both its event detector
+and the snippet cutter are pinned against the reference's own output (tests/golden/events_*.npz,
+tests/golden/chunks_*.npz: `prepare_snippets` / `compute_fitting_event_ranges` of the reference run in
+the build container with inert stubs for the module's tensorflow / keras import lines).
 """
 from __future__ import annotations
 

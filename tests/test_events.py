@@ -1,12 +1,14 @@
 """CPU tests of the host pre-processing row: the C++ event detector against
 fixtures produced by THE REFERENCE's own event_detector.py (tests/golden/make_event_golden.py),
-and invariants of the restated chunker (parity unpinned: data_loader.py cannot be imported)."""
+and the restated chunker against fixtures produced by THE REFERENCE's own data_loader.prepare_snippets
+(tests/golden/make_chunk_golden.py: the module imports with inert stubs for its tensorflow / keras lines)."""
 import os
 
 import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 
 
 @pytest.mark.parametrize("name", ["events_w6_9", "events_w3_6", "events_w6_6"])
@@ -56,3 +58,25 @@ def test_chunker_invariants(rv):
     # padding is the post-padding zero the attention mask keys on (data_loader.py:110-111, utils.py:32)
     k = len(raw_s[0])
     assert (raw[0, k:] == 0).all() and np.allclose(raw[0, :k, 0], raw_s[0][:, 0].astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["chunks_a", "chunks_b", "chunks_c"])
+def test_chunker_matches_reference_fixtures(rv, name):
+    """data_loader.prepare_snippets / compute_fitting_event_ranges against the output of the REFERENCE's own chunker
+    (/root/reference/data_loader.py:29-46,70-108; fixtures by tests/golden/make_chunk_golden.py): window ranges and target
+    strings exact, standard-scaled raw / event features <= 1e-12.  Pins the chunk format T2 and 8f #2."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    dl = rv.data_loader
+    syms = np.array(list(str(g["label_bases"])), dtype=object)
+    raw_s, ev_s, tgt = dl.prepare_snippets(g["signal"], g["label_ranges"], syms, int(g["stride"]))
+    assert [len(s) for s in raw_s] == g["raw_lens"].tolist()          # the chunk ranges, bit-exact
+    assert [len(s) for s in ev_s] == g["ev_lens"].tolist()
+    assert tgt == [str(t) for t in g["targets"]]
+    assert np.abs(np.concatenate(raw_s).ravel() - g["raw_concat"]).max() < 1e-12
+    assert np.abs(np.concatenate(ev_s) - g["ev_concat"]).max() < 1e-12
+    fit = dl.compute_fitting_event_ranges(g["fit_lens"].copy(), int(g["stride"]), raw_max_len=dl.MAX_RAW_LEN)
+    assert np.array_equal(np.asarray(fit, np.int64), g["fit_ranges"])
+    # and the padded slab form of data_loader.py:120-124
+    raw, ev, nuc = dl.snippets_to_slab(raw_s, ev_s, tgt)
+    assert raw.shape == (len(raw_s), 200, 1) and raw.dtype == np.float32 and ev.shape == (len(raw_s), 30, 5) and nuc.dtype == np.int64
+    assert nuc[0, 0] == dl.NUC_TOKEN_START and (nuc[np.arange(len(tgt)), [len(t) - 1 for t in tgt]] == dl.NUC_TOKEN_END).all()

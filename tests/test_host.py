@@ -141,3 +141,53 @@ def test_mapping_evaluator_files_and_paf(rv, tmp_path):
     if shutil.which("minimap2") is None:
         with pytest.raises(RuntimeError, match="minimap2"):
             ev.map_read("ACGT" * 10, "ACGT" * 9)
+
+
+def test_tf_checkpoint_bundle_round_trip(rv, tmp_path):
+    """checkpoint.py: a TF-format tensor bundle (LevelDB-format index + data shard) written with the reference model's
+    variable paths reads back into exactly the weight blob it came from; optimizer slots / counters / the object graph
+    are ignored; CRCs are checked; a wrong shape or a missing variable is an error that names it."""
+    ck = rv.checkpoint
+    cfg = rv.RvConfig(enc_depth=3, dec_depth=2, attention="bahdanau")
+    flat = rv.weights.init_weights(cfg, seed=5)
+    paths = ck.variable_paths(cfg)
+    assert set(paths) == {n for n, _ in rv.weights.blob_layout(cfg)}
+    tensors = {paths[n] + "/.ATTRIBUTES/VARIABLE_VALUE": a for n, a in flat.items()}
+    tensors["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE"] = np.array(1234, np.int64)
+    tensors["decoder/fc/kernel/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE"] = np.zeros((128, 7), np.float32)
+    tensors["save_counter/.ATTRIBUTES/VARIABLE_VALUE"] = np.array(3, np.int64)
+    prefix = str(tmp_path / "model_chp")
+    ck.write_tensor_bundle(prefix, tensors)
+    assert ck.is_tf_checkpoint(prefix) and not ck.is_tf_checkpoint(str(tmp_path / "nothing"))
+    back = ck.read_tensor_bundle(prefix)
+    assert set(back) == set(tensors) and all(np.array_equal(back[k], tensors[k]) and back[k].dtype == tensors[k].dtype for k in tensors)
+    got = ck.flat_from_checkpoint(prefix, cfg)
+    assert np.array_equal(rv.weights.pack(cfg, got), rv.weights.pack(cfg, flat))
+    # a Luong checkpoint has no query layer / attention_v: zeros keep the blob shape
+    cfg_l = rv.RvConfig(enc_depth=3, dec_depth=2)
+    luong = {k: v for k, v in tensors.items() if "query_layer" not in k and "attention_v" not in k}
+    got_l = ck.flat_from_tensors(luong, cfg_l)
+    assert not got_l["W_q"].any() and np.array_equal(got_l["W_mem"], flat["W_mem"])
+    # manifest: offsets tile the blob in blob order
+    man = ck.weights_manifest(cfg)
+    assert [m["segment"] for m in man] == [n for n, _ in rv.weights.blob_layout(cfg)]
+    assert man[-1]["offset_floats"] + man[-1]["count"] == rv.weights.blob_size(cfg)
+    blob = rv.weights.pack(cfg, flat)
+    m = man[7]
+    assert np.array_equal(blob[m["offset_floats"]:m["offset_floats"] + m["count"]].reshape(m["shape"]), flat[m["segment"]])
+    # error paths
+    bad = dict(tensors); bad[paths["W_fc"] + "/.ATTRIBUTES/VARIABLE_VALUE"] = np.zeros((128, 5), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        ck.flat_from_tensors(bad, cfg)
+    few = {k: v for k, v in tensors.items() if "encoder_event/rnn_layers/1/backward_layer/cell/bias" not in k}
+    with pytest.raises(KeyError, match="enc_event.1.bwd.b"):
+        ck.flat_from_tensors(few, cfg)
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read()); raw[100] ^= 0xFF
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="CRC32C"):
+        ck.read_tensor_bundle(prefix)
+    # the committed manifest is the one the code generates for the default model
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "weights_manifest.json")) as f:
+        assert json.load(f)["segments"] == ck.weights_manifest(rv.RvConfig())
