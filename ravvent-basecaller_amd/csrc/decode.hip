@@ -864,8 +864,8 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention; beam search with W <= 8 (W <= 5 with two stacked cells: LDS) and greedy search.
 struct PersistLds {
-  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, total;
-  __host__ __device__ PersistLds(int W, int D = 1) {
+  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, total;
+  __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
     int o = 0;
     attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127)
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
@@ -888,18 +888,24 @@ struct PersistLds {
       cS1 = o; o += 2 * W * RV_U;
       b1s = o; o += RV_G;
     }
+    pq = o; vat = o;
+    if (ATT) {                         // Bahdanau (basecaller.py:131-132): processed query (h . W_q) per beam, and attention_v
+      pq = o; o += W * RV_U;
+      vat = o; o += RV_U;
+    }
     total = o;
   }
 };
 
-template <int W, int NIT, int D>
+template <int W, int NIT, int D, int ATT = 0>
 __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __restrict__ Wcat /*[256,512] = [W_in rows of the attention input ; U]*/,
                                                       const float* __restrict__ Wtok /*[V,512]*/, const float* __restrict__ bdec /*[512]*/,
                                                       const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1,
                                                       const float* __restrict__ Nh /*D == 1: A_h . W_fc [128,V]*/) {
   constexpr int NT = 512;
   extern __shared__ __align__(16) float dsm[];
-  const PersistLds L(W, D);
+  const PersistLds L(W, D, ATT);
+  float* pqs = dsm + L.pq;  float* vat = dsm + L.vat;   // ATT == 1 only
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* ctxp = dsm + L.ctxp;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
@@ -929,7 +935,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const int tc = min(sid + 32 * (2 * p + half), Tm - 1);
       const float* q = cbase + (size_t)tc * RV_E + 16 * s8;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) kr[p][m] = *reinterpret_cast<const float4*>(q + 4 * m);
+      for (int m = 0; m < 4; ++m) {
+        kr[p][m] = *reinterpret_cast<const float4*>(q + 4 * m);
+        if (ATT) {   // Bahdanau: tanh(k + pq) = 1 - 2 / (1 + exp2((k + pq) * 2 log2 e)): the keys carry the factor from here on
+          kr[p][m].x *= 2.0f * LOG2E; kr[p][m].y *= 2.0f * LOG2E; kr[p][m].z *= 2.0f * LOG2E; kr[p][m].w *= 2.0f * LOG2E;
+        }
+      }
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -957,6 +968,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
   if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[i] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
   if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
+  if (ATT && tid < RV_U) vat[tid] = d.v_att[tid] * (-2.0f * LOG2E);   // score = sum_j v_j tanh(.) = const - 2 sum_j v_j / (1 + exp(.)): softmax drops the constant
   if (tid < WB) {
     s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
     s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = tid;
@@ -988,6 +1000,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wa + (size_t)u * RV_U);
     };
+    auto wq_prefetch = [&]() {           // ATT: this thread's slice of W_q (8 rows x 4 columns), requested before the gate math
+      const float* wq = d.W_q + (size_t)(8 * (tid >> 5)) * RV_U + 4 * (tid & 31);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wq + (size_t)u * RV_U);
+    };
+    if (ATT) wq_prefetch();
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
       const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
@@ -1053,6 +1071,38 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       __syncthreads();
     }
+    if (ATT) {
+      // ================= Bahdanau: processed query pq = h . W_q (BahdanauAttention.query_layer, no bias); thread = (4 columns,
+      //   1 of 16 K groups of 8 rows), partial sums through `part` (free between the gates and the context phase)
+      const int d4 = tid & 31, kg = tid >> 5;
+      f2 acc[W][2];
+#pragma unroll
+      for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float hv[WB];
+        *reinterpret_cast<float4*>(hv) = *reinterpret_cast<const float4*>(&hcT[(8 * kg + u) * WB]);
+        if (W > 4) *reinterpret_cast<float4*>(hv + 4) = *reinterpret_cast<const float4*>(&hcT[(8 * kg + u) * WB + 4]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{pw[u].x, pw[u].y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{hv[w], hv[w]}, f2{pw[u].z, pw[u].w}, acc[w][1]);
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        *reinterpret_cast<float4*>(&part[(kg * W + w) * RV_U + 4 * d4]) =
+            make_float4(acc[w][0].x, acc[w][0].y, acc[w][1].x, acc[w][1].y);
+      __syncthreads();
+      for (int i = tid; i < W * RV_U; i += NT) {
+        const int w = i >> 7, col = i & 127;
+        float s0 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s0 += part[(g * W + w) * RV_U + col];
+        pqs[i] = s0 * (2.0f * LOG2E);
+      }
+      __syncthreads();
+    }
     RV_STAMP(d, step, 2);
     // ================= (two cells) attention layer, h part: h . A_h ; thread = (4 columns, 1 of 16 K groups of 8 rows), one batch
     if (D > 1) {
@@ -1087,14 +1137,29 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     for (int w = 0; w < W; ++w) {
       float4 qv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&qp[w * RV_U + 16 * s8 + 4 * m]);
+      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&(ATT ? pqs : qp)[w * RV_U + 16 * s8 + 4 * m]);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         f2 pp = f2{0.f, 0.f};
+        if (ATT) {
+          // Bahdanau, normalize = False: score_t = sum_j v_j tanh(keys_tj + pq_j); keys and pq carry 2 log2(e),
+          // v carries -2 log2(e): score * log2(e) = const + sum_j v'_j / (1 + exp2(k'_tj + pq'_j)), the constant cancels in the softmax
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float4 vv = *reinterpret_cast<const float4*>(&vat[16 * s8 + 4 * m]);
+            const float r0 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].x + qv[m].x));
+            const float r1 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].y + qv[m].y));
+            const float r2 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].z + qv[m].z));
+            const float r3 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].w + qv[m].w));
+            pp = __builtin_elementwise_fma(f2{vv.x, vv.y}, f2{r0, r1}, pp);
+            pp = __builtin_elementwise_fma(f2{vv.z, vv.w}, f2{r2, r3}, pp);
+          }
+        } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           pp = __builtin_elementwise_fma(f2{kr[p][m].x, kr[p][m].y}, f2{qv[m].x, qv[m].y}, pp);
           pp = __builtin_elementwise_fma(f2{kr[p][m].z, kr[p][m].w}, f2{qv[m].z, qv[m].w}, pp);
+        }
         }
         float sw = pp.x + pp.y;
         sw += dpp<0xB1>(sw);    // quad_perm [1,0,3,2]
@@ -1430,25 +1495,26 @@ __global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict
 
 }  // namespace
 
-template <int W, int D>
+template <int W, int D, int ATT>
 static void launch_persist_wd(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                               const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
-  const size_t shm = sizeof(float) * PersistLds(W, D).total;
-  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
-  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
-  else hipLaunchKernelGGL((k_dec_persist<W, 11, D>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
+  const size_t shm = sizeof(float) * PersistLds(W, D, ATT).total;
+  if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
+  else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
+  else hipLaunchKernelGGL((k_dec_persist<W, 11, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
 }
 template <int W>
 static void launch_persist_w(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                              const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
   if constexpr (W <= 5) {
-    if (d.depth > 1) { launch_persist_wd<W, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
+    if (d.depth > 1) { launch_persist_wd<W, 2, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
-  launch_persist_wd<W, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
+  if (d.attention == 1) launch_persist_wd<W, 1, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);     // Bahdanau: one decoder cell
+  else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
-  return d.attention == 0 && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
+  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, d.attention == 1).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
+  return (d.attention == 0 || (d.attention == 1 && d.depth == 1)) && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                         const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
@@ -1536,6 +1602,9 @@ static hipError_t configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
   if constexpr (W <= 5) {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);

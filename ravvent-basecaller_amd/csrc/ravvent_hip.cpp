@@ -358,7 +358,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   const int W_eff = greedy ? 1 : W;
   h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && W_eff <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
   // the persistent decode (decided below, once the decode state is set up) needs neither keys nor the per-step kernels
-  const bool persist_ok = h->opt_persist && h->opt_flash && c.attention == RV_ATT_LUONG && !h->opt_taps && c.dec_depth <= 2 &&
+  const bool persist_ok = h->opt_persist && h->opt_flash && !h->opt_taps && c.dec_depth <= 2 &&
+                          (c.attention == RV_ATT_LUONG || (c.attention == RV_ATT_BAHDANAU && c.dec_depth == 1)) &&
                           W_eff <= (c.dec_depth > 1 ? 5 : 8) && Tm <= 352;
   h->lkeys = ((!h->lflash && !persist_ok) || h->opt_taps) ? 1 : 0;
   if (h->lkeys) {

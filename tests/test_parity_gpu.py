@@ -174,11 +174,54 @@ def test_golden_fixtures_on_gpu(rv, name):
     bc.close()
 
 
+def _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok, ctok, tag=""):
+    """Rows on which the GPU and the fp32 C port disagree are not waved through: each one is re-decoded ALONE by the fp64
+    numpy oracle.  Accepted: the GPU's tokens equal the fp64 tokens (the C port is the one that flipped), or the fp64 decode
+    of that chunk passes through a near-tie -- two of its W + 1 best candidates of some step closer than 1e-4 -- which fp32
+    rounding can legitimately resolve either way.  Anything else fails and prints the row."""
+    same = (tok == ctok).all(axis=1)
+    bad = np.nonzero(~same)[0]
+    assert same.mean() >= 0.95, f"{tag}: only {100 * same.mean():.2f} % rows identical"
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    cfg = bc.cfg.oracle_cfg()
+    end = cfg["end_token"]
+    unexplained = []
+    for b in bad:
+        r1 = raw[b:b + 1] if mode != "event" else None
+        e1 = ev[b:b + 1] if mode != "raw" else None
+        taps = {}
+        otok, _ = oracle.beam_search(w, cfg, r1, e1, W, L, dtype=np.float64, taps=taps)
+        S = otok.shape[1]
+        got = tok[b, :S]
+        if (got == otok[0]).all() and (tok[b, S:] == end).all():
+            continue                                       # GPU == fp64: the C port took the other side of a tie
+        # replay the fp64 beam steps and look for the smallest gap among the W + 1 best candidates of any step
+        lg = taps["step_logits"][:, 0]                     # [S, W, V]
+        log_probs = np.full((1, W), -np.inf); log_probs[0, 0] = 0.0
+        fin = np.zeros((1, W), bool); ln = np.zeros((1, W), np.int64)
+        gap = np.inf
+        for s_ in range(S):
+            lp = oracle.log_softmax(lg[s_][None])
+            row = np.full((lg.shape[2],), oracle.F32_MIN); row[end] = 0.0
+            lp = np.where(fin[..., None], row, lp)
+            total = np.sort((log_probs[..., None] + lp).reshape(-1))[::-1]
+            top = total[:W + 1]
+            top = top[np.isfinite(top)]
+            if top.size > 1:
+                gap = min(gap, float(np.min(-np.diff(top))))
+            _, _, _, log_probs, fin, ln = oracle.beam_search_step(lg[s_][None], log_probs, fin, ln, end)
+        if gap < TOL:
+            continue                                       # a genuine near-tie in the exact arithmetic
+        unexplained.append((int(b), gap, got.tolist(), otok[0].tolist()))
+    assert not unexplained, f"{tag}: rows that differ from fp64 with no near-tie: {unexplained[:3]}"
+    return same, len(bad)
+
+
 # ----------------------------------------------------------------------------------------------
 # BASELINE.json full sizes against the C port of the oracle (numpy is too slow there)
 @pytest.mark.parametrize("B,T_r,T_e,W,L,tag", [
     (64, 300, 30, 1, 48, "C2"), (256, 300, 30, 5, 48, "C3"), (1024, 200, 30, 5, 32, "R"), (67, 123, 17, 4, 20, "ragged")])
-def test_full_size_against_c_port(rv, B, T_r, T_e, W, L, tag):
+def test_full_size_against_c_port(rv, oracle, B, T_r, T_e, W, L, tag):
     from oracle import cpu_port
     bc, _ = _mk(rv, max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L)
     flat = rv.weights.init_weights(bc.cfg, seed=22)
@@ -187,9 +230,9 @@ def test_full_size_against_c_port(rv, B, T_r, T_e, W, L, tag):
     tok, sc = bc.beam_search_prediction((raw, ev), W, L)
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape, tag
-    # fp32-vs-fp32 at 10^5 candidates: allow (and count) near-tie flips instead of demanding 100 %
-    same = (tok.numpy() == ctok).all(axis=1)
-    assert same.mean() >= 0.995, f"{tag}: {100 * same.mean():.2f} % rows identical"
+    # fp32-vs-fp32 at 10^5 candidates: every row that differs must be explained by the fp64 oracle (100 % rows accounted for)
+    same, n_bad = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, tag)
+    print(f"{tag}: {n_bad} of {B} rows differ from the C port, all explained by fp64 near-ties")
     assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL
     # size-independent properties: scores non-increasing, per-base probabilities in (0, 1]
     s = sc.numpy()
@@ -414,7 +457,7 @@ def test_many_reads_share_slabs(rv):
     bc.close()
 
 
-def test_random_shapes_against_c_port(rv):
+def test_random_shapes_against_c_port(rv, oracle):
     """Shape fuzz: ragged batch / time / beam / length combinations in all three input modes."""
     from oracle import cpu_port
     rng = np.random.default_rng(2024)
@@ -431,8 +474,7 @@ def test_random_shapes_against_c_port(rv):
         tok, sc = bc.beam_search_prediction(_inputs(rv, mode, raw, ev), W, L)
         ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
         assert tok.shape == ctok.shape, (case, mode, B, T_r, T_e, W, L)
-        same = (tok.numpy() == ctok).all(axis=1)
-        assert same.mean() >= 0.98, (case, mode, B, T_r, T_e, W, L, same.mean())
+        same, _ = _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok.numpy(), ctok, f"case {case} {mode} {(B, T_r, T_e, W, L)}")
         assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL, (case, mode)
         g, lg = bc.greedy_search_prediction(_inputs(rv, mode, raw, ev), L)
         cg, clg = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, 1, L, greedy=True)
@@ -442,7 +484,7 @@ def test_random_shapes_against_c_port(rv):
 
 
 @pytest.mark.parametrize("W", [5, 8, 1])
-def test_maximum_shapes_against_c_port(rv, W):
+def test_maximum_shapes_against_c_port(rv, oracle, W):
     """The library's limits at once: T_raw + T_event = 352 (all 11 resident row groups of the persistent decode in use),
     max_output_len 64, beam 5 (persistent decode) / 8 (per-step kernels) / 1, a slab larger than the CU count."""
     from oracle import cpu_port
@@ -456,8 +498,7 @@ def test_maximum_shapes_against_c_port(rv, W):
     tok, sc = bc.beam_search_prediction((raw, ev), W, L)
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape
-    same = (tok.numpy() == ctok).all(axis=1)
-    assert same.mean() >= 0.98, same.mean()
+    same, _ = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, f"max shapes W={W}")
     assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL
     with pytest.raises(rv._capi.RavventHipError):
         bc.beam_search_prediction((raw, ev), W, L + 1)
@@ -628,4 +669,44 @@ def test_sharded_two_ranks_on_one_gpu(rv):
     sig, lab = rv.synthetic.make_read(700, seed=4)
     single = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True).run_read(sig, lab, chunk_size=64)
     assert len(single["merged_seq"]) > 30 and out["read"] == single["merged_seq"]
+    bc.close()
+
+
+@pytest.mark.parametrize("B,Tr,Te,W,L", [(9, 120, 20, 5, 20), (6, 300, 30, 5, 24), (5, 40, 8, 1, 12), (4, 60, 0, 8, 14), (3, 307, 45, 3, 10)])
+def test_bahdanau_persistent_decode(rv, oracle, B, Tr, Te, W, L):
+    """Bahdanau attention (Decoder(attention_type='bahdanau'), basecaller.py:131-132; north_star) on the one-launch persistent
+    decode: == the per-step kernels (exact reference dataflow: scores from keys, tanh, context from values) == the fp64
+    oracle; per-step logits of the persistent kernel within 1e-4; greedy logits within 1e-4."""
+    mode = "joint" if Te else "raw"
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, attention_type="bahdanau", honor_attention_type=True,
+                       max_batch=16, max_raw_len=320)
+    flat = rv.weights.init_weights(bc.cfg, seed=19)
+    flat["b_fc"][bc.cfg.end_token] = 0.5
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, max(Te, 1), seed=B + W)
+    raw[1, Tr // 2:] = 0.0
+    x = (raw, ev) if mode == "joint" else raw
+    out = {}
+    bc.set_option("profile", 1)
+    bc.set_option("persist_taps", 1)
+    for persist in (1, 0):
+        bc.set_option("persistent_decode", persist)
+        bc.reset_profile()
+        tok, sc = bc.beam_search_prediction(x, W, L)
+        assert ("dec_persist" in bc.profile()) == bool(persist)
+        out[persist] = (tok.numpy().copy(), sc.numpy().copy())
+        if persist:
+            lg = bc.get_tensor("step_logits").reshape(tok.shape[1], B, W, 7)
+            cs = bc.get_tensor("chunk_steps").astype(int)
+    assert out[1][0].shape == out[0][0].shape and (out[1][0] == out[0][0]).all() and np.abs(out[1][1] - out[0][1]).max() < TOL
+    taps = {}
+    ot, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, W, L, dtype=np.float64, taps=taps)
+    assert out[1][0].shape == ot.shape and (out[1][0] == ot).all() and np.abs(out[1][1] - osc).max() < TOL
+    for b in range(B):
+        assert np.abs(lg[:cs[b], b] - taps["step_logits"][:cs[b], b]).max() < TOL, b
+    bc.set_option("persistent_decode", 1)
+    g, glg = bc.greedy_search_prediction(x, L)
+    og, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, L)
+    assert g.shape == og.shape and (g.numpy() == og).all() and np.abs(glg.numpy() - olg).max() < TOL
     bc.close()
