@@ -863,8 +863,10 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // (end token, unchanged score -- SURVEY.md A.5).  No hipGraph, no per-step launches, no HBM stream:
 // per step the CU pulls only the weights (cell 512 KB + W_mem 128 KB + W_att 192 KB) from L2.
 // Luong attention; beam search with W <= 8 (W <= 5 with two stacked cells: LDS) and greedy search.
+// one decoder cell and W <= 5 leave 48 KB of LDS: 24 of the 256 weight rows the cell product streams from L2 every step stay on chip
+__host__ __device__ constexpr bool persist_weight_cache(int W, int D) { return D == 1 && W <= 5; }
 struct PersistLds {
-  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, total;
+  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, wcache, total;
   __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
     int o = 0;
     attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127)
@@ -893,6 +895,8 @@ struct PersistLds {
       pq = o; o += W * RV_U;
       vat = o; o += RV_U;
     }
+    wcache = o;
+    if (persist_weight_cache(W, D)) o += 24 * RV_G;   // 24 rows of the cell kernel kept in LDS (48 KB): the last 8 rows of K groups 1-3
     total = o;
   }
 };
@@ -906,12 +910,16 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D, ATT);
   float* pqs = dsm + L.pq;  float* vat = dsm + L.vat;   // ATT == 1 only
+  constexpr bool CACHE = persist_weight_cache(W, D);
+  float* wcache = dsm + L.wcache;                        // CACHE only: rows 72 g + 104 + i of Wcat at [(8 g + i) * 512], g = 0..2
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* ctxp = dsm + L.ctxp;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
   float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (spans ctxp + fold)
-  __shared__ float s_wfc[RV_U * RV_MAX_VOCAB + RV_MAX_VOCAB];
-  __shared__ float s_nh[D == 1 ? RV_U * RV_MAX_VOCAB : 1];
+  // output layer weights, transposed to [v][k] (rows padded to 132 floats: the 8-lane groups of two outputs then read different banks)
+  constexpr int FCW = RV_U + 4;
+  __shared__ __align__(16) float s_wfc[RV_MAX_VOCAB * FCW + RV_MAX_VOCAB];
+  __shared__ __align__(16) float s_nh[D == 1 ? RV_MAX_VOCAB * FCW : 4];
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
 
@@ -965,9 +973,16 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     for (int i = tid; i < 3 * W * RV_G; i += NT) partU[i] = 0.f;
     b1s[tid] = bdec1[tid];
   }
-  for (int i = tid; i < RV_U * V; i += NT) s_wfc[i] = d.W_fc[i];
-  if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[i] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
-  if (tid < V) s_wfc[RV_U * V + tid] = d.b_fc[tid];
+  for (int i = tid; i < RV_U * V; i += NT) s_wfc[(i % V) * FCW + i / V] = d.W_fc[i];
+  if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[(i % V) * FCW + i / V] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
+  if (tid < V) s_wfc[RV_MAX_VOCAB * FCW + tid] = d.b_fc[tid];
+  if (CACHE) {
+    for (int i = tid; i < 24 * (RV_G / 4); i += NT) {
+      const int r = i >> 7, c = i & 127;
+      *reinterpret_cast<float4*>(&wcache[r * RV_G + 4 * c]) =
+          *reinterpret_cast<const float4*>(Wcat + (size_t)(72 * (r >> 3) + 104 + (r & 7)) * RV_G + 4 * c);
+    }
+  }
   if (ATT && tid < RV_U) vat[tid] = d.v_att[tid] * (-2.0f * LOG2E);   // score = sum_j v_j tanh(.) = const - 2 sum_j v_j / (1 + exp(.)): softmax drops the constant
   if (tid < WB) {
     s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
@@ -1143,14 +1158,15 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         f2 pp = f2{0.f, 0.f};
         if (ATT) {
           // Bahdanau, normalize = False: score_t = sum_j v_j tanh(keys_tj + pq_j); keys and pq carry 2 log2(e),
-          // v carries -2 log2(e): score * log2(e) = const + sum_j v'_j / (1 + exp2(k'_tj + pq'_j)), the constant cancels in the softmax
+          // v carries -2 log2(e): score * log2(e) = const + sum_j v'_j / (1 + exp2(k'_tj + pq'_j)), the constant cancels in the softmax.
+          // Raw v_exp_f32 (no denormal-range rescue: 1 + e does not see it; +inf gives rcp = 0 = tanh's limit)
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const float4 vv = *reinterpret_cast<const float4*>(&vat[16 * s8 + 4 * m]);
-            const float r0 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].x + qv[m].x));
-            const float r1 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].y + qv[m].y));
-            const float r2 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].z + qv[m].z));
-            const float r3 = __builtin_amdgcn_rcpf(1.0f + exp2f(kr[p][m].w + qv[m].w));
+            const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kr[p][m].x + qv[m].x));
+            const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kr[p][m].y + qv[m].y));
+            const float r2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kr[p][m].z + qv[m].z));
+            const float r3 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kr[p][m].w + qv[m].w));
             pp = __builtin_elementwise_fma(f2{vv.x, vv.y}, f2{r0, r1}, pp);
             pp = __builtin_elementwise_fma(f2{vv.z, vv.w}, f2{r2, r3}, pp);
           }
@@ -1250,17 +1266,29 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const int o8 = tid >> 3, s8 = tid & 7;
       if (o8 < W * V) {                                     // whole 8-lane groups take the branch together
         const int w = o8 / V, v = o8 % V;
-        float p = 0.f;
+        // lane s8 takes k = 16 s8 .. 16 s8 + 15: four float4 of the attention vector against four of the weight row
+        f2 pp = f2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) p = fmaf(att[w * RV_U + 8 * i + s8], s_wfc[(8 * i + s8) * V + v], p);
+        for (int m = 0; m < 4; ++m) {
+          const float4 a4 = *reinterpret_cast<const float4*>(&att[w * RV_U + 16 * s8 + 4 * m]);
+          const float4 w4 = *reinterpret_cast<const float4*>(&s_wfc[v * FCW + 16 * s8 + 4 * m]);
+          pp = __builtin_elementwise_fma(f2{a4.x, a4.y}, f2{w4.x, w4.y}, pp);
+          pp = __builtin_elementwise_fma(f2{a4.z, a4.w}, f2{w4.z, w4.w}, pp);
+        }
         if (D == 1) {                                       // + h . (A_h W_fc)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) p = fmaf(qp[w * RV_U + 8 * i + s8], s_nh[(8 * i + s8) * V + v], p);
+          for (int m = 0; m < 4; ++m) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&qp[w * RV_U + 16 * s8 + 4 * m]);
+            const float4 w4 = *reinterpret_cast<const float4*>(&s_nh[v * FCW + 16 * s8 + 4 * m]);
+            pp = __builtin_elementwise_fma(f2{a4.x, a4.y}, f2{w4.x, w4.y}, pp);
+            pp = __builtin_elementwise_fma(f2{a4.z, a4.w}, f2{w4.z, w4.w}, pp);
+          }
         }
+        float p = pp.x + pp.y;
         p += dpp<0xB1>(p);    // quad_perm [1,0,3,2]
         p += dpp<0x4E>(p);    // quad_perm [2,3,0,1]
         p += dpp<0x141>(p);   // row_half_mirror: the other quad of this 8-lane group
-        if (s8 == 0) lg[w * RV_MAX_VOCAB + v] = p + s_wfc[RV_U * V + v];
+        if (s8 == 0) lg[w * RV_MAX_VOCAB + v] = p + s_wfc[RV_MAX_VOCAB * FCW + v];
       }
     }
     __syncthreads();
@@ -1342,24 +1370,34 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int w = 0; w < W; ++w) { acc[w][0] = f2{0.f, 0.f}; acc[w][1] = f2{0.f, 0.f}; }
       const float* wc = Wcat + 4 * c4;
+      auto fma_row = [&](const float4& wv, const float* xrow) {
+        float xv[WB];
+        *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(xrow);
+        if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(xrow + 4);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wv.x, wv.y}, acc[w][0]);
+          acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wv.z, wv.w}, acc[w][1]);
+        }
+      };
+      const bool cached = CACHE && kg > 0;                  // wave-uniform: K groups 1-3 find their last 8 rows in LDS
+      const int ke_g = cached ? ke - 8 : ke;                // rows streamed from L2
+      if (cached) {                                         // the rows that are already on chip
+        const int kc = ke - 8;
+        const float* xk = kc < RV_U ? attT + kc * WB : hcT + (kc - RV_U) * WB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          fma_row(*reinterpret_cast<const float4*>(&wcache[((kg - 1) * 8 + i) * RV_G + 4 * c4]), xk + i * WB);
+      }
 #pragma unroll 1
-      for (int k0 = kb; k0 < ke; k0 += 8) {                // batches never straddle row 128 (40, 112 and 184 are multiples of 8)
+      for (int k0 = kb; k0 < ke_g; k0 += 8) {               // batches never straddle row 128 (40, 112 and 184 are multiples of 8)
         float4 wr[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)(k0 + i) * RV_G);
         __builtin_amdgcn_sched_barrier(0);
         const float* xk = k0 < RV_U ? attT + k0 * WB : (D > 1 ? h0T : hcT) + (k0 - RV_U) * WB;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float xv[WB];
-          *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(&xk[i * WB]);
-          if (W > 4) *reinterpret_cast<float4*>(xv + 4) = *reinterpret_cast<const float4*>(&xk[i * WB + 4]);
-#pragma unroll
-          for (int w = 0; w < W; ++w) {
-            acc[w][0] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].x, wr[i].y}, acc[w][0]);
-            acc[w][1] = __builtin_elementwise_fma(f2{xv[w], xv[w]}, f2{wr[i].z, wr[i].w}, acc[w][1]);
-          }
-        }
+        for (int i = 0; i < 8; ++i) fma_row(wr[i], xk + i * WB);
       }
 #pragma unroll
       for (int w = 0; w < W; ++w)

@@ -1,7 +1,7 @@
 # Timing ablation of k_dec_attend: RV_ATT_STOP=k makes the kernel return after phase k (results invalid).
 cd /tmp && export TMPDIR=/tmp
 for k in ${STOPS:-1 2 3 4 5 6 7 0}; do
-  RV_ATT_STOP=$k rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/abl$k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline >/dev/null 2>&1
+  RV_ATT_STOP=$k rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/abl$k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras >/dev/null 2>&1
   python3 - $k <<'PY'
 import csv,sys,glob,os
 k=sys.argv[1]

@@ -1,7 +1,7 @@
 # usage: KREGEX=k_dec_attend bash tools/pmc_kernel.sh  -- SQ counters for matching kernels (one pass)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-include-regex "${KREGEX:-k_dec}" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcK -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-include-regex "${KREGEX:-k_dec}" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcK2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-include-regex "${KREGEX:-k_dec}" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcK -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-include-regex "${KREGEX:-k_dec}" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcK2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob,collections,os
 root=os.environ['GRAFT_REPO_ROOT']
