@@ -191,3 +191,31 @@ def test_tf_checkpoint_bundle_round_trip(rv, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "weights_manifest.json")) as f:
         assert json.load(f)["segments"] == ck.weights_manifest(rv.RvConfig())
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without a launcher starts torch.distributed.run as a CHILD process (never an exec) with the
+    same arguments, on 127.0.0.1, relays its stdout and returns its exit code."""
+    import importlib.util
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7, stdout='{"metric": "x"}\n')
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4), ["--gpus", "4", "--steps", "3", "--strong"])
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == ["--gpus", "4", "--steps", "3", "--strong"] and cmd[-6].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # executed-FLOP accounting of the decode: chunk_steps replace B * S
+    assert bench.algorithmic_flops("dec_persist", 4, 300, 30, 5, 47) == 4 * 5 * 47 * (369408 + 768 * 330)
+    assert bench.algorithmic_flops("dec_persist", 4, 300, 30, 5, 47, [47, 10, 12, 47]) == 5 * 116 * (369408 + 768 * 330)
