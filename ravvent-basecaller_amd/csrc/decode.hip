@@ -1448,8 +1448,16 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
   // S: steps the reference loop runs for the WHOLE slab (until every row is finished); So: steps this
   // sub-slab actually ran.  For s in [So, S) all of its beams are finished: the reference emits the
   // end token at an unchanged top-1 score there, which is what is written below.
-  const int S = d.S_dev[0], So = d.chunk_steps ? d.chunk_steps[b] : d.S_dev[1 + d.part];
-  (void)s_S;
+  // persistent decode: S of the slab = the slowest chunk's step count, taken here by every workgroup (B <= a few thousand ints
+  // from L2) instead of in a launch of its own; workgroup 0 leaves it in S_dev for the host
+  if (d.chunk_steps) {
+    int m = 0;
+    for (int i = tid; i < d.B; i += 64) m = max(m, d.chunk_steps[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if (tid == 0) { s_S = m; if (b == 0) { d.S_dev[0] = m; d.S_dev[1] = m; } }
+    __syncthreads();
+  }
+  const int S = d.chunk_steps ? s_S : d.S_dev[0], So = d.chunk_steps ? d.chunk_steps[b] : d.S_dev[1 + d.part];
   int32_t* tk = tokens + (size_t)b * steps;
   if (d.greedy) {
     for (int s = tid; s < steps; s += 64) {
@@ -1520,17 +1528,6 @@ __global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
   if (lane == 0) p.S_dev[0] = S;
 }
 
-// persistent decode: S of the slab = the slowest chunk's step count
-__global__ __launch_bounds__(256) void k_dec_reduce_chunks(const int* __restrict__ chunk_steps, int B, int* __restrict__ S_dev) {
-  __shared__ int sm[4];
-  int m = 0;
-  for (int i = threadIdx.x; i < B; i += 256) m = max(m, chunk_steps[i]);
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) { const int S = max(max(sm[0], sm[1]), max(sm[2], sm[3])); S_dev[0] = S; S_dev[1] = S; }
-}
-
 }  // namespace
 
 template <int W, int D, int ATT>
@@ -1566,7 +1563,7 @@ void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok,
     case 7: launch_persist_w<7>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
     default: launch_persist_w<8>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); break;
   }
-  hipLaunchKernelGGL(k_dec_reduce_chunks, dim3(1), dim3(256), 0, s, d.chunk_steps, d.B, d.S_dev);
+  // (S = max over chunk_steps is taken by k_dec_finalize)
 }
 
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s) {

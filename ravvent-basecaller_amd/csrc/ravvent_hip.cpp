@@ -332,7 +332,17 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
   }
   // ---- _encode_input (basecaller.py:395-416)
-  { Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s); }
+  // The mask is first read by the memory set-up / the decode: it runs on a side stream beside the encoders instead of in front
+  // of them (profiling modes keep it on the main stream so that its events pair up).
+  const bool mask_aside = h->opt_profile == 0 || h->opt_profile == 3;
+  if (mask_aside) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, s));
+    HIPCHK(h, hipStreamWaitEvent(h->side[2], h->ev_fork, 0));     // inputs (H2D copies on s) are in place
+    launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, h->side[2]);
+    HIPCHK(h, hipEventRecord(h->ev_join[2], h->side[2]));
+  } else {
+    Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s);
+  }
   // The two encoders are independent until the time-axis concat (basecaller.py:400-405).
   const bool side_ev = use_raw && use_ev && h->opt_side_ev && c.enc_depth > 1 && !h->opt_fuse;   // (nothing MFMA-bound to hide under once the projection is fused)
   if (side_ev) {
@@ -352,6 +362,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
   }
 
+  if (mask_aside) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[2], 0));
   // ---- setup_memory (basecaller.py:303): keys = (enc_output * mask) . W_mem.  The single-pass Luong
   //      attend never reads keys (score_t = values_t . (W_mem q)); they are built for the two-pass
   //      kernel and for the "keys" debug tap only.
