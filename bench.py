@@ -110,7 +110,7 @@ def cpu_baseline(rv, cfg, flat, T_r, T_e, W, L, sample_chunks=0, target_s=12.0, 
     return out
 
 
-def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False):
+def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent=1):
     """The reference's read-level metric (ravvent_performance_evaluator.py:79,86,125): bases_num / (t_predicting +
     t_postprocessing + t_merge) with bases_num = the read's REFERENCE length, through the evaluator call sequence on one
     synthetic long read (`synthetic.make_read`: ~8,200 chunks of <= 200 samples + <= 30 events, stride 6, cut by the
@@ -128,18 +128,20 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False):
     flat = rv.weights.init_weights(bc.cfg, seed=22, gain=3.0)
     flat["b_fc"][3:7] += 1.5; flat["b_fc"][bc.cfg.end_token] -= 3.0
     bc.set_weights_flat(flat)
-    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=not pipelined, pipelined_merge=pipelined)
+    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=not pipelined, pipelined_merge=pipelined, concurrent_slabs=concurrent)
     e.run_slabs(raw[:slab], ev[:slab], nuc[:slab], chunk_size=slab)          # warm-up
     best = None
     for _ in range(3):
         r = e.run_slabs(raw, ev, nuc, bases_num=n_bases, chunk_size=slab)
         if best is None or r["total_processing"] < best["total_processing"]:
             best = r
+    e.close()
     bc.close()
     tp, n_chunks = best["total_processing"], best["chunks_num"]
     return {"workload": f"one synthetic read of {n_bases} bases -> {n_chunks} chunks (joint <=200+<=30, stride 6), beam 5, L {L}, slabs "
                         f"of {slab}, base-emitting weights, fused post-processing + C++ merger"
-                        + (" pipelined behind the GPU" if pipelined else ""),
+                        + (" pipelined behind the GPU" if pipelined else "")
+                        + (f", {concurrent} handles decoding consecutive slabs at once" if concurrent > 1 else ""),
             "kbases_per_s": round(n_bases / tp / 1000.0, 2), "chunks_per_s": round(n_chunks / tp, 1),
             "bases_num": n_bases, "merged_bases": len(best["merged_seq"]),
             "t_predicting": round(best["t_predicting"], 5), "t_postprocessing": round(best["t_postprocessing"], 5),
@@ -396,6 +398,7 @@ def main():
             try:
                 out["read_level"] = read_level(rv, local)
                 out["read_level_pipelined"] = read_level(rv, local, pipelined=True)
+                out["read_level_concurrent"] = read_level(rv, local, pipelined=True, concurrent=2)
                 out["bahdanau"] = bahdanau_timing(rv, local, B, T_r, T_e, W, L)
             except Exception as e:
                 out["extras_error"] = repr(e)

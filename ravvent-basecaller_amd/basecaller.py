@@ -103,6 +103,23 @@ class Basecaller:
         blob = _weights.pack(self.cfg, flat)
         self._check(self._lib.rv_load_weights(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size),
                     "rv_load_weights")
+        self._blob = blob
+
+    def clone(self):
+        """A second handle on the same device with the same configuration and weights (own stream, own buffers): two handles
+        driven from two host threads keep the GPU fed across slab boundaries (evaluator.PerformanceEvaluator(concurrent_slabs=2))."""
+        other = object.__new__(Basecaller)
+        for k, v in self.__dict__.items():
+            if k not in ("_h", "_outs"):
+                setattr(other, k, v)
+        other._h = ctypes.c_void_p()
+        ccfg = self.cfg.to_c()
+        rc = self._lib.rv_create(ctypes.byref(ccfg), ctypes.byref(other._h))
+        _capi.check(self._lib, None, rc, "rv_create")
+        if getattr(self, "_blob", None) is not None:
+            other._check(self._lib.rv_load_weights(other._h, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size),
+                         "rv_load_weights")
+        return other
 
     def load_weights(self, path):
         """ravvent_performance_evaluator.py:107.  `path` is either a TF-format checkpoint prefix as Keras writes it

@@ -15,7 +15,8 @@ from . import merger, utils
 
 
 class PerformanceEvaluator:
-    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False, pipelined_merge: bool = False):
+    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False, pipelined_merge: bool = False,
+                 concurrent_slabs: int = 1):
         self.basecaller = basecaller
         self.stride = stride           # ravvent_performance_evaluator.py:16
         # True: strings + per-base probabilities come straight from the device (rv_beam_search_calls)
@@ -24,6 +25,17 @@ class PerformanceEvaluator:
         # True: slab k is stitched on a host thread (rv_merger_append) while the GPU decodes slab k+1; implies the
         # fused post-processing.  t_merge is then the part of the merge the GPU work did not hide.
         self.pipelined_merge = pipelined_merge
+        # > 1 (with pipelined_merge): that many handles (`Basecaller.clone`) decode consecutive slabs at the same time, each from
+        # its own host thread: slab k + 1's encoders fill the CUs slab k's decode leaves as its chunks finish, and no launch gap or
+        # host copy leaves the GPU idle.  Results are identical (slabs are independent); t_predicting is then wall time.
+        self.concurrent_slabs = max(1, int(concurrent_slabs))
+        self._clones = []
+
+    def close(self):
+        """Release the extra handles of `concurrent_slabs` (the caller's own Basecaller stays open)."""
+        for bc in self._clones:
+            bc.close()
+        self._clones = []
 
     @staticmethod
     def _split_into_chunks(arr, def_chunk_size):
@@ -171,18 +183,39 @@ class PerformanceEvaluator:
 
     def _run_pipelined(self, data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width, t_data_loading):
         from concurrent.futures import ThreadPoolExecutor
+        import queue
         sm = merger.StreamingMerger(self.merger.scores_id, self.merger.overlap_seq_len)
         kept, pending = [], []
         t_predicting = 0.0
-        with ThreadPoolExecutor(max_workers=1) as pool:          # one worker: slabs are appended in read order
-            for data in data_chunks:
-                start = timer()
-                input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
-                arrays = self.basecaller.beam_search_call_arrays(input_data, beam_width=beam_width,
-                                                                 max_output_len=target_data.shape[1])
-                t_predicting += timer() - start
-                kept.append(arrays)
-                pending.append(pool.submit(sm.append, *arrays))
+        K = self.concurrent_slabs if hasattr(self.basecaller, "clone") else 1
+        while len(self._clones) < K - 1:
+            self._clones.append(self.basecaller.clone())
+        handles = queue.SimpleQueue()
+        for bc in [self.basecaller] + self._clones[:K - 1]:
+            handles.put(bc)
+        mode = self.basecaller.input_data_type
+
+        def decode(data):
+            bc = handles.get()
+            try:
+                input_data, target_data = utils.unpack_data_to_input_target(data, mode)
+                return bc.beam_search_call_arrays(input_data, beam_width=beam_width, max_output_len=target_data.shape[1])
+            finally:
+                handles.put(bc)
+        with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=K) as gpu_pool:   # merge worker: slabs appended in read order
+            start = timer()
+            if K == 1:
+                for data in data_chunks:
+                    arrays = decode(data)
+                    kept.append(arrays)
+                    pending.append(pool.submit(sm.append, *arrays))
+            else:
+                futs = [gpu_pool.submit(decode, data) for data in data_chunks]
+                for f in futs:                                   # in read order, as they complete
+                    arrays = f.result()
+                    kept.append(arrays)
+                    pending.append(pool.submit(sm.append, *arrays))
+            t_predicting = timer() - start
             start = timer()
             for f in pending:
                 f.result()

@@ -425,6 +425,12 @@ def test_evaluator_call_sequence(rv):
     assert fused["merged_seq"] == res["merged_seq"]
     piped = rv.evaluator.PerformanceEvaluator(bc, pipelined_merge=True).run_slabs(raw, ev, nuc, chunk_size=64)
     assert piped["merged_seq"] == res["merged_seq"] and [p[0] for p in piped["nuc_preds"]] == [p[0] for p in res["nuc_preds"]]
+    # two handles decoding consecutive slabs at the same time from two host threads: same calls, same read
+    ev2 = rv.evaluator.PerformanceEvaluator(bc, pipelined_merge=True, concurrent_slabs=2)
+    conc = ev2.run_slabs(raw, ev, nuc, chunk_size=32)
+    assert conc["merged_seq"] == rv.evaluator.PerformanceEvaluator(bc, pipelined_merge=True).run_slabs(raw, ev, nuc, chunk_size=32)["merged_seq"]
+    assert [p[0] for p in conc["nuc_preds"]] == [p[0] for p in res["nuc_preds"]]
+    ev2.close()
     bc.close()
 
 

@@ -16,6 +16,10 @@ def mk(seed):
     bc.reuse_output_buffers = True
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=seed)
     return bc, (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
+# warm the GPU up first (clocks ramp over the first tens of milliseconds of load)
+_w, _x = mk(99)
+for _ in range(60): _w.beam_search_prediction(_x, W, L)
+_w.close()
 for K in (1, 2, 3):
     hs = [mk(i) for i in range(K)]
     for bc, x in hs:
