@@ -30,12 +30,21 @@ def _collective_device(like: torch.Tensor, group=None, device=None) -> torch.dev
     return torch.device("cpu")
 
 
+_INDEX: dict = {}
+
+
 def _read_order_index(n_total: int, world: int, n_max: int, dev) -> torch.Tensor:
-    rows = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        rows.append(torch.arange(r * n_max, r * n_max + (hi - lo), device=dev))
-    return torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long, device=dev)
+    """Rows of the rank-major gathered buffer in read order (cached: it only depends on the shapes)."""
+    key = (n_total, world, n_max, str(dev))
+    if key not in _INDEX:
+        if len(_INDEX) > 64:
+            _INDEX.clear()
+        rows = []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            rows.append(torch.arange(r * n_max, r * n_max + (hi - lo), device=dev))
+        _INDEX[key] = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long, device=dev)
+    return _INDEX[key]
 
 
 _BUFFERS: dict = {}
@@ -69,8 +78,10 @@ def gather_calls(tokens: torch.Tensor, scores: torch.Tensor, steps: int, n_total
     cols = 2 * max_steps + 1
     packed, gathered = _buffers("calls", max(n_max, 1), cols, world, dev)
     n_loc, s_loc = tokens.shape
-    packed[:, :max_steps] = end_token
-    packed[:, max_steps:] = 0
+    full = n_loc == packed.shape[0] and s_loc == max_steps      # the usual case: every cell of `packed` is overwritten below
+    if not full:
+        packed[:, :max_steps] = end_token
+        packed[:, max_steps:2 * max_steps] = 0
     packed[:, 2 * max_steps] = int(steps)
     if n_loc and s_loc:
         packed[:n_loc, :s_loc] = tokens.to(dev, torch.int32)
@@ -80,9 +91,12 @@ def gather_calls(tokens: torch.Tensor, scores: torch.Tensor, steps: int, n_total
             packed[:n_loc, max_steps + s_loc:2 * max_steps] = sc[:, s_loc - 1:s_loc].view(torch.int32)
     dist.all_gather_into_tensor(gathered, packed, group=group)
     S = int(gathered[:, 2 * max_steps].max().item()) if n_total else 0
-    idx = _read_order_index(n_total, world, max(n_max, 1), dev)
-    out = gathered[idx]
-    return out[:, :S].contiguous(), out[:, max_steps:max_steps + S].contiguous().view(torch.float32)
+    if n_total == world * packed.shape[0]:                      # equal shards: the gathered rows already are in read order
+        out = gathered
+    else:
+        out = gathered[_read_order_index(n_total, world, packed.shape[0], dev)]
+    # fresh tensors: `gathered` is a cached buffer the next call overwrites
+    return out[:, :S].clone(), out[:, max_steps:max_steps + S].clone().view(torch.float32)
 
 
 def _decode_shard(basecaller, raw, event, lo, hi, beam_width, max_output_len, slab):
