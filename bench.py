@@ -189,7 +189,11 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    sys.stdout.write(p.stdout)
+    for line in p.stdout.splitlines():          # ONE JSON line on stdout; whatever else the ranks printed there (gloo's connection
+        if line.startswith('{"metric"'):        # notices, ...) goes to stderr
+            sys.stdout.write(line + "\n")
+        else:
+            sys.stderr.write(line + "\n")
     sys.stdout.flush()
     return p.returncode
 

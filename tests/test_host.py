@@ -206,11 +206,15 @@ def test_bench_self_launch_command(monkeypatch):
 
     def fake_run(cmd, env=None, stdout=None, text=None):
         seen["cmd"], seen["env"] = cmd, env
-        return types.SimpleNamespace(returncode=7, stdout='{"metric": "x"}\n')
+        return types.SimpleNamespace(returncode=7, stdout='[Gloo] Rank 0 is connected\n{"metric": "x"}\n')
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import io
+    out = io.StringIO()
+    monkeypatch.setattr(bench.sys, "stdout", out)
     rc = bench.self_launch(types.SimpleNamespace(gpus=4), ["--gpus", "4", "--steps", "3", "--strong"])
-    assert rc == 7
+    monkeypatch.undo()
+    assert rc == 7 and out.getvalue() == '{"metric": "x"}\n'      # exactly one JSON line reaches stdout
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
