@@ -1,0 +1,44 @@
+"""Build-level guard (CPU, hipcc cross-compiles gfx950 here): the hot kernels sit at the edge of the register file -- the persistent
+decode keeps a chunk's attention memory in 184 of its 256 VGPRs, the fused recurrence + projection kernel has 168 -- and a change
+that tips the register allocator over does not fail any parity test: it silently spills the resident rows to scratch and the
+kernel runs 1.5x slower (seen three times in round 2).  This test compiles the two kernel files for the device only and bounds the
+scratch of the instantiations the benchmark workloads launch."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ravvent-basecaller_amd", "csrc")
+
+# kernel-name regex -> max bytes of scratch per lane
+LIMITS = {
+    r"k_dec_persistILi5ELi11ELi1ELi0E": 64,      # C3: Luong, beam 5, T_m <= 352 (36 B today)
+    r"k_dec_persistILi5ELi8ELi1ELi0E": 0,        # R: T_m <= 256
+    r"k_dec_persistILi5ELi11ELi1ELi1E": 64,      # C3 with Bahdanau (28 B today)
+    r"k_lstm_rec_projILi2EE": 0,                 # C3 fused recurrence + projection
+    r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_hot_kernels_do_not_spill(tmp_path):
+    found = {}
+    for src, extra in (("decode.hip", []), ("lstm_rec.hip", ["-fno-slp-vectorize"])):
+        out = tmp_path / (src + ".s")
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra,
+                        os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
+        text = out.read_text()
+        for m in re.finditer(r"^(_Z\w+):", text, re.M):
+            tail = text[text.index(".Lfunc_end", m.start()):][:4000]
+            sc = re.search(r"; ScratchSize: (\d+)", tail)
+            vg = re.search(r"; NumVgprs: (\d+)", tail)
+            if sc:
+                found[m.group(1)] = (int(sc.group(1)), int(vg.group(1)))
+    for pat, limit in LIMITS.items():
+        hits = {k: v for k, v in found.items() if re.search(pat, k)}
+        assert hits, f"no kernel matches {pat}"
+        for name, (scratch, vgpr) in hits.items():
+            assert scratch <= limit, f"{name}: {scratch} B of scratch per lane ({vgpr} VGPRs) > {limit}: the resident rows are being spilled"

@@ -716,3 +716,26 @@ def test_bahdanau_persistent_decode(rv, oracle, B, Tr, Te, W, L):
     og, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, L)
     assert g.shape == og.shape and (g.numpy() == og).all() and np.abs(glg.numpy() - olg).max() < TOL
     bc.close()
+
+
+def test_chunks_never_interact_at_full_size(rv):
+    """Size-independent property at BASELINE's C3 size: a chunk decoded inside a 256-chunk slab (two rows per recurrence workgroup,
+    one of 256 decode workgroups) and the same chunk decoded ALONE (one row per workgroup) give the same tokens and the same
+    scores -- the per-row arithmetic does not depend on the slab around it; only the slab-wide step count S differs, and beyond
+    a chunk's own last step the slab row holds the end token at an unchanged score."""
+    B, T_r, T_e, W, L = 256, 300, 30, 5, 48
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L)
+    flat = rv.weights.init_weights(bc.cfg, seed=22)
+    flat["b_fc"][bc.cfg.end_token] = 0.3            # chunks stop at different steps
+    bc.set_weights_flat(flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=5)
+    tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+    tok, sc = tok.numpy(), sc.numpy()
+    end = bc.cfg.end_token
+    for b in (0, 1, 2, 77, 128, 200, 254, 255):
+        t1, s1 = bc.beam_search_prediction((raw[b:b + 1], ev[b:b + 1]), W, L)
+        t1, s1 = t1.numpy()[0], s1.numpy()[0]
+        n = t1.shape[0]
+        assert n <= tok.shape[1] and (tok[b, :n] == t1).all() and np.array_equal(sc[b, :n], s1), b
+        assert (tok[b, n:] == end).all() and (sc[b, n:] == s1[-1]).all(), b
+    bc.close()
