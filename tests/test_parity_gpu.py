@@ -174,12 +174,16 @@ def test_golden_fixtures_on_gpu(rv, name):
     bc.close()
 
 
-def _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok, ctok, tag=""):
-    """Rows on which the GPU and the fp32 C port disagree are not waved through: each one is re-decoded ALONE by the fp64
-    numpy oracle.  Accepted: the GPU's tokens equal the fp64 tokens (the C port is the one that flipped), or the fp64 decode
-    of that chunk passes through a near-tie -- two of its W + 1 best candidates of some step closer than 1e-4 -- which fp32
-    rounding can legitimately resolve either way.  Anything else fails and prints the row."""
+def _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok, ctok, tag="", sc=None, csc=None):
+    """Rows on which the GPU and the fp32 C port disagree -- in their tokens, or (tokens equal) in the per-step top-1 scores by
+    1e-4 or more -- are not waved through: each one is re-decoded ALONE by the fp64 numpy oracle.  Accepted: the GPU's tokens and
+    scores equal the fp64 ones (the C port is the one that flipped), or the fp64 decode of that chunk passes through a near-tie --
+    two of its W + 1 best candidates of some step closer than 1e-4 -- which fp32 rounding can legitimately resolve either way
+    (a different beam set after the cut also changes the later top-1 scores, which are not back-traced: SURVEY.md A.5).
+    Anything else fails and prints the row.  Returns the mask of rows that agree outright and the number that needed explaining."""
     same = (tok == ctok).all(axis=1)
+    if sc is not None:
+        same &= np.abs(sc - csc).max(axis=1, initial=0.0) < TOL
     bad = np.nonzero(~same)[0]
     assert same.mean() >= 0.95, f"{tag}: only {100 * same.mean():.2f} % rows identical"
     w = rv.weights.flat_to_nested(bc.cfg, flat)
@@ -190,10 +194,11 @@ def _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok, ctok, ta
         r1 = raw[b:b + 1] if mode != "event" else None
         e1 = ev[b:b + 1] if mode != "raw" else None
         taps = {}
-        otok, _ = oracle.beam_search(w, cfg, r1, e1, W, L, dtype=np.float64, taps=taps)
+        otok, osc = oracle.beam_search(w, cfg, r1, e1, W, L, dtype=np.float64, taps=taps)
         S = otok.shape[1]
         got = tok[b, :S]
-        if (got == otok[0]).all() and (tok[b, S:] == end).all():
+        if got.shape[0] == S and (got == otok[0]).all() and (tok[b, S:] == end).all() and \
+                (sc is None or np.abs(sc[b, :S] - osc[0]).max(initial=0.0) < TOL):
             continue                                       # GPU == fp64: the C port took the other side of a tie
         # replay the fp64 beam steps and look for the smallest gap among the W + 1 best candidates of any step
         lg = taps["step_logits"][:, 0]                     # [S, W, V]
@@ -231,9 +236,8 @@ def test_full_size_against_c_port(rv, oracle, B, T_r, T_e, W, L, tag):
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape, tag
     # fp32-vs-fp32 at 10^5 candidates: every row that differs must be explained by the fp64 oracle (100 % rows accounted for)
-    same, n_bad = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, tag)
-    print(f"{tag}: {n_bad} of {B} rows differ from the C port, all explained by fp64 near-ties")
-    assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL
+    same, n_bad = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, tag, sc.numpy(), csc)
+    print(f"{tag}: {n_bad} of {B} rows differ from the C port (tokens, or scores by >= 1e-4), all explained by the fp64 oracle")
     # size-independent properties: scores non-increasing, per-base probabilities in (0, 1]
     s = sc.numpy()
     assert (np.diff(s, axis=1) <= 1e-6).all()
@@ -480,8 +484,7 @@ def test_random_shapes_against_c_port(rv, oracle):
         tok, sc = bc.beam_search_prediction(_inputs(rv, mode, raw, ev), W, L)
         ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
         assert tok.shape == ctok.shape, (case, mode, B, T_r, T_e, W, L)
-        same, _ = _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok.numpy(), ctok, f"case {case} {mode} {(B, T_r, T_e, W, L)}")
-        assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL, (case, mode)
+        _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok.numpy(), ctok, f"case {case} {mode} {(B, T_r, T_e, W, L)}", sc.numpy(), csc)
         g, lg = bc.greedy_search_prediction(_inputs(rv, mode, raw, ev), L)
         cg, clg = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, 1, L, greedy=True)
         assert g.shape == cg.shape and np.abs(lg.numpy() - clg)[(g.numpy() == cg).all(axis=1)].max() < TOL
@@ -504,8 +507,7 @@ def test_maximum_shapes_against_c_port(rv, oracle, W):
     tok, sc = bc.beam_search_prediction((raw, ev), W, L)
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape
-    same, _ = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, f"max shapes W={W}")
-    assert np.abs(sc.numpy()[same] - csc[same]).max() < TOL
+    _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, f"max shapes W={W}", sc.numpy(), csc)
     with pytest.raises(rv._capi.RavventHipError):
         bc.beam_search_prediction((raw, ev), W, L + 1)
     bc.close()
