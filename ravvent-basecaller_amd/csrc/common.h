@@ -17,7 +17,8 @@ struct RecArgs {
   const float* x;        // F>0: chunk input [B,T,F];  F==0: pre-projected xw [B,T,2,512] (bias folded)
   const float* W[2];     // F>0: input kernel [F,512] per direction
   const float* bias[2];  // F>0: [512] per direction
-  const float* U[2];     // recurrent kernel [128,512] per direction
+  const float* U[2];     // recurrent kernel [128,512] per direction (blob order)
+  const float* Up[2];    // the same kernel in the recurrence's register order: [32 i][512 threads] float4 = (slot 0..3 of k = 32 kq + i), slot r = gate (kq + r) & 3 of unit j; thread = 4 j + kq
   const float* Wp[2];    // fused-projection kernel only: input kernel [256,512] as MFMA B fragments [32 tiles][16 k-groups][64 lanes][4]
   const float* h0[2];    // initial states [B,128] or nullptr (zeros)
   const float* c0[2];

@@ -41,14 +41,16 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
   // ---- recurrent kernel slice -> registers.  Slot r of lane kq holds gate (kq + r) & 3, so the
   // quad reduce-scatter below lands gate kq's full sum in lane kq with three DPP adds and no selects.
   // Slots are paired (0,1) / (2,3) for v_pk_fma_f32: plain v_fma_f32 runs at half the fp32 rate.
+  // (Up = U pre-arranged at load time in this register order, [32 i][512 threads] float4: the 256 KB slice arrives as 32 coalesced
+  //  1-KB loads per wave instead of 128 strided dwords per lane -- the prologue of every recurrence launch)
   f2 u01[32], u23[32];
   {
-    const float* Ud = a.U[dir] + (32 * kq) * RV_G + j;
-    const int g0 = kq * RV_U, g1 = ((kq + 1) & 3) * RV_U, g2 = ((kq + 2) & 3) * RV_U, g3 = ((kq + 3) & 3) * RV_U;
+    const float4* Up = reinterpret_cast<const float4*>(a.Up[dir]) + tid;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      u01[i] = f2{Ud[i * RV_G + g0], Ud[i * RV_G + g1]};
-      u23[i] = f2{Ud[i * RV_G + g2], Ud[i * RV_G + g3]};
+      const float4 v = Up[i * 512];
+      u01[i] = f2{v.x, v.y};
+      u23[i] = f2{v.z, v.w};
     }
   }
   const float am = kq == 2 ? 2.f : 1.f;      // own gate: tanh (c~) for kq == 2, sigmoid otherwise
@@ -311,12 +313,12 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
   float c[BT], hlast[BT];
   const float am = kq == 2 ? 2.f : 1.f;
   {
-    const float* Ud = a.U[dir] + (32 * kq) * RV_G + j;
-    const int g0 = kq * RV_U, g1 = ((kq + 1) & 3) * RV_U, g2 = ((kq + 2) & 3) * RV_U, g3 = ((kq + 3) & 3) * RV_U;
+    const float4* Up = reinterpret_cast<const float4*>(a.Up[dir]) + tid;      // tid < 512 in this role
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      u01[i] = f2{Ud[i * RV_G + g0], Ud[i * RV_G + g1]};
-      u23[i] = f2{Ud[i * RV_G + g2], Ud[i * RV_G + g3]};
+      const float4 v = Up[i * 512];
+      u01[i] = f2{v.x, v.y};
+      u23[i] = f2{v.z, v.w};
     }
 #pragma unroll
     for (int r = 0; r < BT; ++r) {

@@ -55,6 +55,7 @@ struct RvContext {
   int lpersist = 0;
   int opt_flash = 1;                        // single-pass Luong attend (two-pass when 0 / Bahdanau)
   int lflash = 0, lkeys = 0, lsplit = 1;
+  float* d_Up = nullptr;                    // derived: recurrent kernels in the recurrence kernels' register order, [enc][layer][dir][65536]
   float* d_Wp = nullptr;                    // derived: input kernels of encoder layers >= 1 as MFMA B fragments, [enc][layer-1][dir][131072]
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
@@ -228,6 +229,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
     for (int dr = 0; dr < 2; ++dr) {
       const LstmW& w = h->enc[e][l][dr];
       a.U[dr] = w.U;
+      a.Up[dr] = h->d_Up + ((size_t)(e * depth + l) * 2 + dr) * RV_U * RV_G;
       a.h0[dr] = l > 0 ? h->st[e][rd][2 * dr] : nullptr;
       a.c0[dr] = l > 0 ? h->st[e][rd][2 * dr + 1] : nullptr;
       a.hT[dr] = h->st[e][wr][2 * dr];
@@ -591,6 +593,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
+  TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
@@ -693,6 +696,21 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
         for (int n = 0; n < RV_G; ++n) t[(size_t)n * RV_E + k] = blob[off + (size_t)k * RV_G + n];
       HIPCHK(h, hipMemcpy(h->d_WcatT + (size_t)l * RV_G * RV_E, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    // every encoder layer: U [128][512] -> [32 i][512 threads][4 slots] (thread = 4 j + kq holds k = 32 kq + i, slot r = gate (kq + r) & 3)
+    for (int e = 0; e < 2; ++e)
+      for (int l = 0; l < h->cfg.enc_depth; ++l)
+        for (int dr = 0; dr < 2; ++dr) {
+          const size_t off = (size_t)(h->enc[e][l][dr].U - h->d_w);
+          std::vector<float> up((size_t)RV_U * RV_G);
+          for (int i = 0; i < 32; ++i)
+            for (int tid = 0; tid < 512; ++tid) {
+              const int j = tid >> 2, kq = tid & 3;
+              for (int r = 0; r < 4; ++r)
+                up[((size_t)i * 512 + tid) * 4 + r] = blob[off + (size_t)(32 * kq + i) * RV_G + ((kq + r) & 3) * RV_U + j];
+            }
+          float* dst = h->d_Up + ((size_t)(e * h->cfg.enc_depth + l) * 2 + dr) * RV_U * RV_G;
+          HIPCHK(h, hipMemcpy(dst, up.data(), up.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     // encoder layers >= 1: W [256][512] -> [32 column tiles][16 k-groups][64 lanes][4]: lane (q = lane/16, col = lane%16)
     // of tile nt finds W[16 g + 4 i + q][16 nt + col] for its 4 MFMAs i of k-group g in one float4 (lstm_rec.hip)
     for (int e = 0; e < 2; ++e)
