@@ -924,7 +924,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
 
   const int b = blockIdx.x, tid = threadIdx.x, Tm = d.Tm, V = d.V;
-  const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
+  const int lane = tid & 63, sub = lane & 15, sid = tid >> 4;
   const size_t row0 = (size_t)b * W;
   const int steps = d.L - 1;
 

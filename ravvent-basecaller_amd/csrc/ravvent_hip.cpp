@@ -586,7 +586,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   HIPTRY(configure_rec_kernels());
   const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
   const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
-  const size_t Tm = Tr + Te, Tx = std::max(Tr, Te), L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
+  const size_t Tm = Tr + Te, L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
