@@ -116,6 +116,9 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "fused_projection" (0/1, default 1: encoder layers >= 1 compute their input projection inside the
  *                       recurrence kernel, on MFMA waves of the same workgroup; 0 = separate GEMM launch + pre-projected
  *                       tensor; results agree to fp32 rounding),
+ *          "tail_wave"  (0/1, default 1: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
+ *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
+ *                       agree to fp32 rounding),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

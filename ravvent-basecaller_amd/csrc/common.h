@@ -27,6 +27,8 @@ struct RecArgs {
   float* out;            // [B,out_T,256]; direction d writes columns [128d,128d+128) at time out_t0+t
   int out_T, out_t0;
   int B, T;
+  long long* dbg_ts;     // diagnostic builds (-DRV_REC_STAMPS, env RV_REC_STAMPS): [24] per-wave {busy, barrier-wait} cycle sums of workgroup (0,0)
+  int tail_wave;         // layer 0 (F > 0), rows_per_block >= 2: the cell update runs on a ninth wave (k_lstm_rec_tw)
   int dbg_role;          // timing probe only (RV_DBG_ROLE): 1 = projection waves skip their math, 2 = recurrence waves skip theirs
 };
 // F in {0,1,5}; rows_per_block in {1,2,4,8}

@@ -174,6 +174,167 @@ __global__ __launch_bounds__(512) void k_lstm_rec(RecArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Layer 0 with the CELL UPDATE ON FOUR EXTRA WAVES.  In k_lstm_rec every one of the 8 waves spends ~40 % of its instruction stream on
+// the serial tail of a row (one activation per lane, quad all-gather, a cell update replicated over the quad, tanh, stores): a wave
+// issues one VALU instruction per ~5-9 cycles whatever it is, so the step is the sum of two such streams per SIMD.  Here the 8
+// U-holding waves only take the packed FMAs and the quad reduce-scatter and leave the four gate sums of every unit in LDS (zs);
+// waves 8-11 -- one per SIMD, no U, one unit per lane -- do the cell update of 32 units each (5 exp + 5 rcp + ~12 VALU per row, instead
+// of 8 waves x 25 instructions) and publish h.  The BT rows run as two groups half a step apart, so the tail waves work on one
+// group while the FMA waves are in the other group's product: two barriers per step.  (One tail wave for all 128 units makes ITS
+// SIMD the straggler of every phase: measured slower than the 8-wave kernel.)
+#ifdef RV_REC_STAMPS
+#define RV_TW_STAMP_INIT() long long ts_busy = 0, ts_wait = 0, ts_a = __builtin_readcyclecounter()
+#define RV_TW_BARRIER() do { const long long tb_ = __builtin_readcyclecounter(); __syncthreads(); const long long tc_ = __builtin_readcyclecounter(); \
+                             ts_busy += tb_ - ts_a; ts_wait += tc_ - tb_; ts_a = tc_; } while (0)
+#define RV_TW_STAMP_OUT() do { if (a.dbg_ts && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) { \
+                                 a.dbg_ts[2 * (threadIdx.x >> 6)] = ts_busy; a.dbg_ts[2 * (threadIdx.x >> 6) + 1] = ts_wait; } } while (0)
+#else
+#define RV_TW_STAMP_INIT() do {} while (0)
+#define RV_TW_BARRIER() __syncthreads()
+#define RV_TW_STAMP_OUT() do {} while (0)
+#endif
+
+template <int BT, int F>
+__global__ __launch_bounds__(768) void k_lstm_rec_tw(RecArgs a) {
+  static_assert(BT >= 2 && BT % 2 == 0 && F > 0, "two row groups; layer 0 only");
+  constexpr int H = BT / 2;
+  constexpr int KH = H >= 2 ? H / 2 : 1;  // rows of a group per tail lane (lanes 0-31 take even rows of the group, 32-63 odd ones)
+  extern __shared__ __align__(16) float smem[];
+  float* hs = smem;                       // [BT][128]   h per row (single-buffered: written in the phase after the one that read it)
+  float* zs = hs + BT * RV_U;             // [BT][512]   gate sums per row, [gate][unit]
+  float* xs = zs + BT * RV_G;             // [BT][T*F]
+
+  const int tid = threadIdx.x;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * BT;
+  const int T = a.T, per = T * F;
+  for (int r = 0; r < BT; ++r) {          // stage the chunks' input windows, coalesced (all 12 waves)
+    const int b = min(b0 + r, a.B - 1);
+    for (int i = tid; i < per; i += 768) xs[r * per + i] = a.x[(size_t)b * per + i];
+  }
+
+  if (tid >= 512) {
+    // ---------------- tail waves: wave 8 + w owns units 32 w .. 32 w + 31; lane half = which rows of a group
+    const int l = tid & 63, unit = 32 * ((tid - 512) >> 6) + (l & 31), rsel = l >> 5;
+    const bool active = H >= 2 || rsel == 0;
+    // The VALU arbiter serves waves by priority, then age, and these are the youngest waves of their SIMDs: at equal priority their
+    // ~45 instructions per step get the leftover issue slots and finish LAST (stamps: busy 2,265 of 2,540 cycles per step, the
+    // whole workgroup waiting at the barrier for them).  They are short: give them the slots when they want them.
+    __builtin_amdgcn_s_setprio(3);
+    float c[2][KH], hl[2][KH];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const int r = g * H + (H >= 2 ? 2 * k + rsel : 0);
+        const int b = min(b0 + r, a.B - 1);
+        c[g][k] = a.c0[dir] ? a.c0[dir][(size_t)b * RV_U + unit] : 0.f;
+        hl[g][k] = a.h0[dir] ? a.h0[dir][(size_t)b * RV_U + unit] : 0.f;
+        if (active) hs[r * RV_U + unit] = hl[g][k];
+      }
+    auto tail = [&](int g, int t) {
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const int r = g * H + (H >= 2 ? 2 * k + rsel : 0);
+        const float* z = zs + r * RV_G + unit;
+        const float cc = fmaf(rv_sigmoid(z[RV_U]), c[g][k], rv_sigmoid(z[0]) * rv_tanh(z[2 * RV_U]));
+        const float hh = rv_sigmoid(z[3 * RV_U]) * rv_tanh(cc);
+        c[g][k] = cc; hl[g][k] = hh;
+        if (active) {
+          hs[r * RV_U + unit] = hh;
+          if (b0 + r < a.B) a.out[((size_t)(b0 + r) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + unit] = hh;
+        }
+      }
+    };
+    __syncthreads();                                       // initial state in LDS
+    __syncthreads();                                       // FMA waves: z(G0, step 0)
+    RV_TW_STAMP_INIT();
+    for (int s = 0; s < T; ++s) {
+      const int t = dir ? T - 1 - s : s;
+      tail(0, t);                                          // phase B(s): G0's tail beside G1's product
+      RV_TW_BARRIER();
+      tail(1, t);                                          // phase A(s + 1): G1's tail beside G0's next product
+      RV_TW_BARRIER();
+    }
+    RV_TW_STAMP_OUT();
+    if (active) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+          const int r = g * H + (H >= 2 ? 2 * k + rsel : 0);
+          if (b0 + r < a.B) {
+            a.hT[dir][(size_t)(b0 + r) * RV_U + unit] = hl[g][k];
+            a.cT[dir][(size_t)(b0 + r) * RV_U + unit] = c[g][k];
+          }
+        }
+    }
+    return;
+  }
+
+  // ---------------- FMA waves (thread = unit j x K quarter kq, U slice in registers as in k_lstm_rec)
+  const int j = tid >> 2, kq = tid & 3;
+  if (tid >= 256) __builtin_amdgcn_s_setprio(1);           // the second-dispatched half loses every arbitration at equal priority
+  f2 u01[32], u23[32];
+  {
+    const float4* Up = reinterpret_cast<const float4*>(a.Up[dir]) + tid;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float4 v = Up[i * 512];
+      u01[i] = f2{v.x, v.y};
+      u23[i] = f2{v.z, v.w};
+    }
+  }
+  float wx[F], bx;
+#pragma unroll
+  for (int f = 0; f < F; ++f) wx[f] = a.W[dir][f * RV_G + kq * RV_U + j];
+  bx = a.bias[dir][kq * RV_U + j];
+  auto gate_sum = [&](int r, int t) {                       // lane kq leaves gate kq of unit j in zs[r]
+    float xv = bx;
+#pragma unroll
+    for (int f = 0; f < F; ++f) xv = fmaf(xs[r * per + t * F + f], wx[f], xv);
+    f2 a01 = f2{xv, 0.f}, a23 = f2{0.f, 0.f};
+    const float4* hp = reinterpret_cast<const float4*>(hs + r * RV_U + 32 * kq);
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) {
+      const float4 hv = hp[i4];
+      a01 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u01[4 * i4 + 0], a01);
+      a23 = __builtin_elementwise_fma(f2{hv.x, hv.x}, u23[4 * i4 + 0], a23);
+      a01 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u01[4 * i4 + 1], a01);
+      a23 = __builtin_elementwise_fma(f2{hv.y, hv.y}, u23[4 * i4 + 1], a23);
+      a01 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u01[4 * i4 + 2], a01);
+      a23 = __builtin_elementwise_fma(f2{hv.z, hv.z}, u23[4 * i4 + 2], a23);
+      a01 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u01[4 * i4 + 3], a01);
+      a23 = __builtin_elementwise_fma(f2{hv.w, hv.w}, u23[4 * i4 + 3], a23);
+    }
+    float zz = a01.x + quad_perm<0x39>(a23.y);
+    zz += quad_perm<0x4E>(a23.x);
+    zz += quad_perm<0x93>(a01.y);
+    zs[r * RV_G + kq * RV_U + j] = zz;
+    if (H > 1) __builtin_amdgcn_sched_barrier(0);           // one row's h reads and accumulators live at a time
+  };
+  __syncthreads();                                         // initial state in LDS
+  {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < H; ++r) gate_sum(r, t0);
+  }
+  __syncthreads();
+  RV_TW_STAMP_INIT();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int tn = dir ? max(t - 1, 0) : min(t + 1, T - 1);  // the last step's look-ahead is computed and dropped
+#pragma unroll
+    for (int r = H; r < BT; ++r) gate_sum(r, t);           // phase B(s): G1's product for step s (h of G1 from phase A(s))
+    RV_TW_BARRIER();
+#pragma unroll
+    for (int r = 0; r < H; ++r) gate_sum(r, tn);           // phase A(s + 1): G0's product for step s + 1 (h of G0 from phase B(s))
+    RV_TW_BARRIER();
+  }
+  RV_TW_STAMP_OUT();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Layers >= 1 with the input projection computed IN the recurrence kernel, on the matrix pipe.
 // The standalone K0 GEMM leaves the VALU idle and the recurrence leaves the MFMA pipe idle; here one
 // 768-thread workgroup holds both: waves 0-7 are the recurrence above (same registers, same math),
@@ -404,8 +565,24 @@ void launch_one(const RecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((k_lstm_rec<BT, F>), grid, dim3(512), shm, s, a);
 }
 
+template <int BT, int F>
+void launch_tw(const RecArgs& a, hipStream_t s) {
+  dim3 grid((a.B + BT - 1) / BT, 2);
+  const size_t shm = sizeof(float) * ((size_t)BT * RV_U + (size_t)BT * RV_G + (size_t)BT * a.T * F);
+  hipLaunchKernelGGL((k_lstm_rec_tw<BT, F>), grid, dim3(768), shm, s, a);
+}
+
 template <int F>
 void launch_f(const RecArgs& a, int bt, hipStream_t s) {
+  if constexpr (F > 0) {
+    if (a.tail_wave && bt >= 2) {
+      switch (bt) {
+        case 2: launch_tw<2, F>(a, s); return;
+        case 4: launch_tw<4, F>(a, s); return;
+        default: launch_tw<8, F>(a, s); return;
+      }
+    }
+  }
   switch (bt) {
     case 1: launch_one<1, F>(a, s); break;
     case 2: launch_one<2, F>(a, s); break;

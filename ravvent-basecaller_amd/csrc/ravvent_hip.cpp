@@ -57,6 +57,7 @@ struct RvContext {
   int lflash = 0, lkeys = 0, lsplit = 1;
   float* d_Up = nullptr;                    // derived: recurrent kernels in the recurrence kernels' register order, [enc][layer][dir][65536]
   float* d_Wp = nullptr;                    // derived: input kernels of encoder layers >= 1 as MFMA B fragments, [enc][layer-1][dir][131072]
+  int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
   float* d_Wmp = nullptr;                   // derived: [W_mem | A_c] [256][256] (A_c = W_att rows 128..383): projection of the attention memory for the persistent decode
@@ -87,6 +88,7 @@ struct RvContext {
   int *d_clen = nullptr, *pin_clen = nullptr;
 
   int opt_taps = 0, opt_graph = 1, opt_profile = 0;
+  long long* rec_ts = nullptr;              // diagnostic: per-wave cycle sums of the raw layer-0 recurrence (RV_REC_STAMPS)
   int opt_ptaps = 0, lptaps = 0;            // persist_taps: per-step logits of the persistent decode (debug)
   std::map<std::string, ProfEntry> prof;
   struct Pending { std::string name; hipEvent_t a, b; };
@@ -239,7 +241,10 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       a.x = x;
       for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
       Scope sc(h, e == 0 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0", s);
+      a.tail_wave = h->opt_tail_wave;
+      a.dbg_ts = e == 0 ? h->rec_ts : nullptr;
       launch_lstm_rec(a, F, bt, s);
+      a.dbg_ts = nullptr;
     } else {
       const float* in = h->act[e][(l - 1) & 1];
       if (h->opt_fuse) {   // x . W + b on the matrix pipe inside the recurrence kernel: no K0 launch, no xw tensor
@@ -615,6 +620,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
   DecState& d = h->dec_st;
   if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
+  if (getenv("RV_REC_STAMPS")) TRY(dalloc(h, &h->rec_ts, 24));
   if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
   d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
   TRY(dalloc(h, &d.xh, c.dec_depth * N * RV_E));
@@ -802,6 +808,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "persistent_decode")) h->opt_persist = value != 0;
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
+  else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");
     h->opt_att_nt = value;
@@ -822,6 +829,15 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
   else if (!strcmp(name, "keys")) {
     if (!h->lkeys) return fail(h, RV_ESTATE, "keys were not built by the last call (single-pass attend); set debug_taps=1");
     src = h->keys; n = B * Tm * RV_U;
+  }
+  else if (!strcmp(name, "rec_stamps")) {
+    if (!h->rec_ts) return fail(h, RV_ESTATE, "set RV_REC_STAMPS=1 before rv_create (and load a -DRV_REC_STAMPS build)");
+    long long ts[24];
+    HIPCHK(h, hipMemcpy(ts, h->rec_ts, sizeof ts, hipMemcpyDeviceToHost));
+    *n_written = 24;
+    if (!dst || dst_floats < 24) return fail(h, RV_EINVAL, "rec_stamps needs 24 floats");
+    for (int i = 0; i < 24; ++i) dst[i] = (float)ts[i];
+    return RV_OK;
   }
   else if (!strcmp(name, "dbg_stamps")) {
     if (!d.dbg_ts) return fail(h, RV_ESTATE, "set RV_DBG_STAMPS=1 before rv_create");
