@@ -20,6 +20,7 @@ LIMITS = {
     r"k_dec_persistILi5ELi11ELi1ELi1E": 64,      # C3 with Bahdanau (28 B today)
     r"k_lstm_rec_projILi2EE": 0,                 # C3 fused recurrence + projection
     r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
+    r"k_lstm_rec_twILi2ELi1EE": 0, r"k_lstm_rec_twILi2ELi5EE": 0,   # C3 layer 0 (tail-wave variant)
 }
 
 
