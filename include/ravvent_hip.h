@@ -116,6 +116,10 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "fused_projection" (0/1, default 1: encoder layers >= 1 compute their input projection inside the
  *                       recurrence kernel, on MFMA waves of the same workgroup; 0 = separate GEMM launch + pre-projected
  *                       tensor; results agree to fp32 rounding),
+ *          "split_projection" (0/1/2, default 2: the fused projection runs on 16-bit MFMAs with both operands cut into parts
+ *                       whose products are exact in f32.  2 = two f16 parts of the scaled operands (2^14 x, and W scaled per
+ *                       column by a power of two), three products: operands held to 2^-23, what f32 holds; 1 = three bf16
+ *                       parts, six products; 0 = v_mfma_f32_16x16x4_f32 on the f32 operands.  Results agree to f32 rounding),
  *          "tail_wave"  (0/1, default 1: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
  *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
  *                       agree to fp32 rounding),

@@ -20,6 +20,8 @@ struct RecArgs {
   const float* U[2];     // recurrent kernel [128,512] per direction (blob order)
   const float* Up[2];    // the same kernel in the recurrence's register order: [32 i][512 threads] float4 = (slot 0..3 of k = 32 kq + i), slot r = gate (kq + r) & 3 of unit j; thread = 4 j + kq
   const float* Wp[2];    // fused-projection kernel only: input kernel [256,512] as MFMA B fragments [32 tiles][16 k-groups][64 lanes][4]
+  const uint16_t* Wsb[2];  // the same kernel as three bf16 parts for the split-bf16 projection, [32 tiles][3 parts][8 k-steps][64 lanes][8]; null = f32 MFMA
+  const uint16_t* Wh[2];   // ... as two f16 parts of the column-scaled kernel, [32 tiles][2 parts][8 k-steps][64 lanes][8], then 512 floats 2^-14 / s_n; takes precedence over Wsb
   const float* h0[2];    // initial states [B,128] or nullptr (zeros)
   const float* c0[2];
   float* hT[2];          // final states [B,128]
@@ -54,6 +56,10 @@ struct GemmArgs {
   const int* skip_flag; int skip_when;   // if skip_flag && *skip_flag >= skip_when: kernel exits
 };
 void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s);
+// C[M,256] = A[M,256] . Wmp[256,256] on split-f16 MFMAs; img = [8 k-steps][16 tiles][2 parts][64 lanes][8 f16] of the column-scaled
+// kernel, then 256 floats 2^-14 / s_n (RV_WMP16_SLOT uint16).  Precondition: |A| <= 1 (rows of an LSTM layer's output).
+#define RV_WMP16_SLOT ((size_t)2 * RV_E * RV_E + 2 * RV_E)
+void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s);
 
 // ---------------------------------------------------------------- small encoder-side kernels
 void launch_input_mask(const float* raw, const float* ev, int B, int T_r, int T_e, float pad,

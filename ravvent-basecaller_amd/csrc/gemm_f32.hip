@@ -145,3 +145,108 @@ void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, s, a);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// K2s -- the attention-memory projection  C[M,256] = A[M,256] . Wmp[256,256]  on v_mfma_f32_16x16x32_f16 with both
+// operands cut into two f16 parts (the split of lstm_rec.hip's SB = 2, without the 2^11 on the low part: with the operands
+// scaled up by 2^14 the low parts sit far above the f16 subnormals on their own).  a' = 2^14 a (|a| <= 1: rows of the
+// encoder output), w' = s_n w (s_n: the power of two that brings column n's largest weight into [2^13, 2^14));
+// a'.w' = ah.wh + ah.wl + al.wh (+ al.wl, below 2^-22 of the product, dropped), every f16 x f16 product exact in f32, one
+// f32 accumulator.  3 MFMAs of 16 cycles per 16x16x32 block instead of 8 v_mfma_f32_32x32x2_f32 of 64: the f32 form is
+// MFMA-bound at ~0.13 ms on the C3 slab, this one is bound by its HBM bytes (A once, C once).
+//
+// Workgroup = 4 waves, 128 rows x all 256 columns; a wave owns 32 rows (two 16-row tiles) x 16 column tiles = 128
+// accumulator registers.  K runs in 8 steps of 32: the step's B slab (16 tiles x 2 parts x 1 KB, fragment order, built at
+// load time) is staged through LDS, double-buffered, and shared by the four waves; A fragments go from global memory
+// straight to registers (a lane reads the 8 consecutive floats of its row that its fragment holds) and are split there.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void k_gemm_mem_split(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
+                                                           float* __restrict__ C) {
+  __shared__ __align__(16) char Bs[2][32768];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * 128 + 32 * wave;
+  const int q = lane >> 4;
+  const float* arow[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) arow[m] = A + (size_t)min(r0 + 16 * m + (lane & 15), M - 1) * RV_E + 8 * q;
+
+  f4v acc[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  float4 bst[4];                                           // half of the next B slab on its way to LDS
+  auto b_load = [&](int ks, int half) {
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + (size_t)ks * 32768 + half * 16384) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bst[i] = src[256 * i];
+  };
+  auto b_store = [&](int buf, int half) {
+    float4* dst = reinterpret_cast<float4*>(Bs[buf] + half * 16384) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[256 * i] = bst[i];
+  };
+  float4 ar[2][2];                                         // the next k-step's A floats
+  auto a_load = [&](int ks) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      ar[m][0] = *reinterpret_cast<const float4*>(arow[m] + 32 * ks);
+      ar[m][1] = *reinterpret_cast<const float4*>(arow[m] + 32 * ks + 4);
+    }
+  };
+  b_load(0, 0); b_store(0, 0); b_load(0, 1); b_store(0, 1); a_load(0);
+  __syncthreads();
+  for (int ks = 0; ks < 8; ++ks) {
+    h8 ah[2], al[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float v[8] = {ar[m][0].x, ar[m][0].y, ar[m][0].z, ar[m][0].w, ar[m][1].x, ar[m][1].y, ar[m][1].z, ar[m][1].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s = v[j] * 16384.f;
+        ah[m][j] = (_Float16)s;
+        al[m][j] = (_Float16)(s - (float)ah[m][j]);        // exact residual, then one rounding
+      }
+    }
+    const bool more = ks + 1 < 8;
+    if (more) { b_load(ks + 1, 0); a_load(ks + 1); }
+    const char* bs = Bs[ks & 1] + lane * 16;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int nt = 8 * hf; nt < 8 * hf + 8; ++nt) {
+        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][nt], 0, 0, 0);
+        }
+      }
+      // the other buffer was last read in step ks - 1, which every wave left through the barrier below
+      if (more) { b_store((ks + 1) & 1, hf); if (hf == 0) b_load(ks + 1, 1); }
+    }
+    __syncthreads();
+  }
+  // C/D map of the 16x16 tile: col = lane % 16, row = 4 (lane / 16) + i; the column factors 2^-14 / s_n follow the image
+  const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) {
+    const int col = 16 * nt + (lane & 15);
+    const float f = cs[col];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 16 * m + 4 * q + i;
+        if (row < M) C[(size_t)row * RV_E + col] = acc[m][nt][i] * f;
+      }
+  }
+}
+
+void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
+  hipLaunchKernelGGL(k_gemm_mem_split, dim3((M + 127) / 128), dim3(256), 0, s, A, M, img, C);
+}

@@ -20,6 +20,11 @@
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 template <int CTRL>
 __device__ __forceinline__ float quad_perm(float v) {   // DPP quad_perm, CTRL = sel0 | sel1<<2 | sel2<<4 | sel3<<6
@@ -345,15 +350,35 @@ __global__ __launch_bounds__(768) void k_lstm_rec_tw(RecArgs a) {
 // double-buffered, fragment-ordered LDS image; every projection wave finishes 8 of the 32 column
 // tiles, one (tile, K-half) unit per chunk per step, reading its B fragments as one float4 per lane
 // per 4 MFMAs from a weight image pre-arranged at load time (Wp: [tile][k-group][lane][4]).
-template <int BT>
+//
+// SB = 1 ("split bf16"): the same product on v_mfma_f32_16x16x32_bf16 -- 16x the MACs per clock of the f32 form.  Both
+// operands are cut into three bf16 parts (x = xh + xm + xl exactly: 3 x 8 significant bits, round-to-nearest residuals;
+// W likewise, once, at load time) and six of the nine part products are summed in f32, smallest first:
+// (xh.wl + xl.wh + xm.wm) + (xh.wm + xm.wh) + xh.wh.  Every bf16 x bf16 product is exact in f32; the three dropped products
+// are below 2^-23 of |x.w|, the size of the rounding of one f32 product.  48 MFMAs of 16 cycles per 16x16 tile instead of
+// 64 of 32, and each holds the SIMD's vector issue for 8 cycles, not 32: the recurrence waves get the SIMD back.
+// A image: [part][k-step 8][k-quarter 4][row 16][8 bf16] (+16 B per 256-B block), B image Wsb: [tile][part][k-step][lane][8 bf16].
+//
+// SB = 2 ("split f16"): two f16 parts per operand and three products, on v_mfma_f32_16x16x32_f16.  x' = 2^14 x (|x| <= 1: x
+// is the output of an LSTM layer) and w' = s_n w (s_n = the power of two that brings column n's largest weight into
+// [2^13, 2^14]) are cut as v = vh + 2^-11 vl with vh = f16(v), vl = f16(2^11 (v - vh)): 11 + 11 significant bits and the sign
+// of the residual, a relative error below 2^-23 -- the operand as f32 holds it, to within its last bit.  The scaling keeps
+// both parts of every operand that matters out of the f16 subnormals (threshold 2^-28 of the column's largest weight).
+// x'.w' = xh.wh + 2^-11 (xh.wl + xl.wh) [+ 2^-22 xl.wl, dropped]; every f16 x f16 product is exact in f32.  24 MFMAs of
+// 16 cycles per tile, and 4 bytes of weight image per element where the bf16 form reads 6: the projection waves stream
+// their B fragments from L2 every block, and at 16 rows per fragment that stream (29 B/clk/CU is what L2 delivers) is
+// what bounds this role.  Image Wh: [tile][part 2][k-step 8][lane 64][8 f16], then 512 floats 2^-14 / s_n.
+template <int BT, int SB>
 __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
   constexpr int TBK = 16 / BT;                 // timesteps per projected block (16 MFMA rows)
   constexpr int XG = 260;                      // k-group stride of the A image (256 + 4: the transposing stores hit 2 banks deep, not 16)
+  constexpr int NP = SB == 2 ? 2 : 3;          // parts per operand
+  constexpr int XSB = 272, XSP = 32 * XSB, XSBUF = NP * XSP;   // split image: bytes per (k-step, k-quarter) block / per part / per buffer
   extern __shared__ __align__(16) float smem[];
   float* hs = smem;                            // [2][BT][128]
   float* xwb = hs + 2 * BT * RV_U;             // [2][16 rows][512]   projected inputs, row = s_local*BT + r
-  float* bsm = xwb + 2 * 16 * RV_G;            // [512] bias of this direction
-  float* xa = bsm + RV_G;             // [2][16 k-groups][4 q][16 rows][4 i]  A fragments: lane (q, row) reads one float4
+  float* bsm = xwb + 2 * 16 * RV_G;            // [512] bias of this direction, [512] column scales (SB = 2)
+  float* xa = bsm + 2 * RV_G;             // [2][16 k-groups][4 q][16 rows][4 i]  A fragments: lane (q, row) reads one float4
 
   const int tid = threadIdx.x;
   const int dir = blockIdx.y;
@@ -375,6 +400,32 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
     }
   };
   auto a_store = [&](int blk, const float4* v) {
+    if constexpr (SB) {
+      char* dst = reinterpret_cast<char*>(xa) + (blk & 1) * XSBUF;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int idx = p + 256 * f, rho = idx >> 6, k4 = idx & 63;      // k = 4 k4: block k4/2 = 4 (k/32) + (k%32)/8, half k4&1
+        char* q0 = dst + (k4 >> 1) * XSB + rho * 16 + (k4 & 1) * 8;
+        f2 r0 = f2{v[f].x, v[f].y}, r1 = f2{v[f].z, v[f].w};
+        if constexpr (SB == 2) {
+          r0 *= 16384.f; r1 *= 16384.f;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {
+            const h2 c0 = __builtin_convertvector(r0, h2), c1 = __builtin_convertvector(r1, h2);
+            *reinterpret_cast<uint2*>(q0 + part * XSP) = uint2{__builtin_bit_cast(unsigned, c0), __builtin_bit_cast(unsigned, c1)};
+            r0 = (r0 - __builtin_convertvector(c0, f2)) * 2048.f; r1 = (r1 - __builtin_convertvector(c1, f2)) * 2048.f;   // exact
+          }
+        } else {
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            const bf2 c0 = __builtin_convertvector(r0, bf2), c1 = __builtin_convertvector(r1, bf2);
+            *reinterpret_cast<uint2*>(q0 + part * XSP) = uint2{__builtin_bit_cast(unsigned, c0), __builtin_bit_cast(unsigned, c1)};
+            r0 -= __builtin_convertvector(c0, f2); r1 -= __builtin_convertvector(c1, f2);   // exact: the residual fits f32
+          }
+        }
+      }
+      return;
+    }
     float* dst = xa + (blk & 1) * (16 * XG);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -389,13 +440,101 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
   // allocation of the recurrence (128 VGPRs of U) apart from the projection's fragments.
   if (proj) {
     const int lane = tid & 63, pw = p >> 6;             // projection wave 0..3 owns column tiles 8 pw .. 8 pw + 7
-    typedef float f4v __attribute__((ext_vector_type(4)));
     f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float4 av[4];                                       // activations of a later block in flight
     a_load(0, av); a_store(0, av);
     if (nblk > 1) { a_load(1, av); a_store(1, av); }
     bsm[p] = a.bias[dir][p]; bsm[p + 256] = a.bias[dir][p + 256];
+    if constexpr (SB == 2) {                              // 2^-14 / s_n behind the bias
+      const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.Wh[dir]) + (size_t)2 * RV_E * RV_G * 2);
+      bsm[RV_G + p] = cs[p]; bsm[RV_G + p + 256] = cs[p + 256];
+    }
     __syncthreads();
+    if constexpr (SB) {
+      // unit = (column tile, K half) as below: 4 k-steps x 6 (3) part products = 24 (12) MFMAs; the B parts of the NEXT unit
+      // are requested before this unit's MFMAs (4 NP x 16 B per lane), the A parts are read from LDS one k-step at a time.
+      f4v accs = {0.f, 0.f, 0.f, 0.f}, accm = {0.f, 0.f, 0.f, 0.f}, acch = {0.f, 0.f, 0.f, 0.f};
+      const char* wimg = reinterpret_cast<const char*>(SB == 2 ? a.Wh[dir] : a.Wsb[dir]);
+      auto b_issue = [&](int unit, float4* bf) {          // bf[4 part + ks]
+        const int nt = 8 * pw + ((unit & 15) >> 1), kh = unit & 1;
+        const char* bp = wimg + ((size_t)(nt * NP) * 8 + 4 * kh) * 1024 + lane * 16;
+#pragma unroll
+        for (int part = 0; part < NP; ++part)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) bf[4 * part + ks] = *reinterpret_cast<const float4*>(bp + (size_t)(part * 8 + ks) * 1024);
+      };
+      auto proj_unit = [&](int blk, int unit, const float4* bf, float4* bf_next) {
+        const int nt = 8 * pw + (unit >> 1), kh = unit & 1;
+        b_issue(unit + 1, bf_next);
+        const char* ap = reinterpret_cast<const char*>(xa) + (blk & 1) * XSBUF + (16 * kh + (lane >> 4)) * XSB + (lane & 15) * 16;
+        if (kh == 0) { accs = f4v{0.f, 0.f, 0.f, 0.f}; accm = accs; acch = accs; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float4 af[NP];
+#pragma unroll
+          for (int part = 0; part < NP; ++part) af[part] = *reinterpret_cast<const float4*>(ap + part * XSP + ks * 4 * XSB);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SB == 2) {
+            const h8 ah = __builtin_bit_cast(h8, af[0]), al = __builtin_bit_cast(h8, af[1]);
+            const h8 bh = __builtin_bit_cast(h8, bf[ks]), bl = __builtin_bit_cast(h8, bf[4 + ks]);
+            accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accm, 0, 0, 0);
+            acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acch, 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accs, 0, 0, 0);
+          } else {
+            const bf8 ah = __builtin_bit_cast(bf8, af[0]), am = __builtin_bit_cast(bf8, af[1]), al = __builtin_bit_cast(bf8, af[2]);
+            const bf8 bh = __builtin_bit_cast(bf8, bf[ks]), bm = __builtin_bit_cast(bf8, bf[4 + ks]), bl = __builtin_bit_cast(bf8, bf[8 + ks]);
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, accs, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, accm, 0, 0, 0);
+            acch = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acch, 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, accs, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, accm, 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, accs, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kh == 1) {                                     // tile done: + bias -> LDS (C/D map: col = lane%16, row = 4*(lane/16)+i)
+          const int col = 16 * nt + (lane & 15);
+          const float bb = bsm[col];
+          float* dst = xwb + (blk & 1) * (16 * RV_G) + (4 * (lane >> 4)) * RV_G + col;
+          if constexpr (SB == 2) {
+            const float cs = bsm[RV_G + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i * RV_G] = fmaf(fmaf(accs[i] + accm[i], 0x1p-11f, acch[i]), cs, bb);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i * RV_G] = ((accs[i] + accm[i]) + acch[i]) + bb;
+          }
+        }
+      };
+      float4 bfa[4 * NP], bfb[4 * NP];
+      b_issue(0, bfa);
+      RV_TW_STAMP_INIT();
+      for (int s = -TBK; s < T; ++s) {
+        const int blk = s >= 0 ? s / TBK : -1;
+        const int sl = s - blk * TBK;
+        const int nb = blk + 1;
+        if (nb < nblk && a.dbg_role != 1) {
+          if (BT == 1) {
+            proj_unit(nb, sl, bfa, bfb);
+#pragma unroll
+            for (int g = 0; g < 4 * NP; ++g) bfa[g] = bfb[g];
+          } else {
+#pragma unroll
+            for (int u = 0; u < BT; u += 2) {
+              proj_unit(nb, sl * BT + u, bfa, bfb);
+              proj_unit(nb, sl * BT + u + 1, bfb, bfa);
+            }
+          }
+        }
+        if (nb >= 1 && nb + 1 < nblk) {
+          if (sl == 0) a_load(nb + 1, av);
+          if (sl == TBK - 1) a_store(nb + 1, av);
+        }
+        RV_TW_BARRIER();
+      }
+      RV_TW_STAMP_OUT();
+      return;
+    }
     // One projection "unit" = (column tile, K half): 8 k-groups = 32 MFMAs.  A block needs 16 units per wave;
     // BT of them run per step, so block n+1 is complete exactly when the recurrence finishes block n.
     // This wave is alone with its MFMAs on its SIMD, so nothing hides its load latency: the B fragments of the
@@ -490,10 +629,11 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
     }
   }
   __syncthreads();
-  for (int s = -TBK; s < 0; ++s) __syncthreads();       // block 0 is being projected
+  RV_TW_STAMP_INIT();
+  for (int s = -TBK; s < 0; ++s) RV_TW_BARRIER();       // block 0 is being projected
   int cur = 0;
   for (int s = 0; s < T; ++s) {
-    if (a.dbg_role == 2) { __syncthreads(); continue; }
+    if (a.dbg_role == 2) { RV_TW_BARRIER(); continue; }
     const int blk = s / TBK, sl = s - blk * TBK;
     const int t = dir ? T - 1 - s : s;
     const float* hc = hs + cur * BT * RV_U;
@@ -539,8 +679,9 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
       }
     }
     cur ^= 1;
-    __syncthreads();
+    RV_TW_BARRIER();
   }
+  RV_TW_STAMP_OUT();
   if (kq == 0) {
 #pragma unroll
     for (int r = 0; r < BT; ++r)
@@ -551,11 +692,15 @@ __global__ __launch_bounds__(768) void k_lstm_rec_proj(RecArgs a) {
   }
 }
 
+constexpr size_t proj_lds_bytes(int bt, int split) {
+  return sizeof(float) * (2 * bt * RV_U + 2 * 16 * RV_G + 2 * RV_G) + (split ? 2 * (split == 2 ? 2 : 3) * 32 * 272 : sizeof(float) * 2 * 16 * 260);
+}
 template <int BT>
 void launch_proj(const RecArgs& a, hipStream_t s) {
   dim3 grid((a.B + BT - 1) / BT, 2);
-  const size_t shm = sizeof(float) * (2 * BT * RV_U + 2 * 16 * RV_G + RV_G + 2 * 16 * 260);
-  hipLaunchKernelGGL((k_lstm_rec_proj<BT>), grid, dim3(768), shm, s, a);
+  if (a.Wh[0]) hipLaunchKernelGGL((k_lstm_rec_proj<BT, 2>), grid, dim3(768), proj_lds_bytes(BT, 2), s, a);
+  else if (a.Wsb[0]) hipLaunchKernelGGL((k_lstm_rec_proj<BT, 1>), grid, dim3(768), proj_lds_bytes(BT, 1), s, a);
+  else hipLaunchKernelGGL((k_lstm_rec_proj<BT, 0>), grid, dim3(768), proj_lds_bytes(BT, 0), s, a);
 }
 
 template <int BT, int F>
@@ -602,10 +747,14 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s) {
   }
 }
 hipError_t configure_rec_kernels() {
-  const int shm = (int)(sizeof(float) * (2 * 8 * RV_U + 2 * 16 * RV_G + RV_G + 2 * 16 * 260));
+  const int shm = (int)proj_lds_bytes(8, 1);             // the largest of the three images
   hipError_t first = hipSuccess;
-  for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_proj<1>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2>),
-                        reinterpret_cast<const void*>(&k_lstm_rec_proj<4>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8>)}) {
+  for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_proj<1, 0>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2, 0>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<4, 0>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8, 0>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<1, 1>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2, 1>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<4, 1>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8, 1>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<1, 2>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2, 2>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_proj<4, 2>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8, 2>)}) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     if (e != hipSuccess && first == hipSuccess) first = e;
   }

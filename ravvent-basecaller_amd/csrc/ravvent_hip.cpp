@@ -57,12 +57,16 @@ struct RvContext {
   int lflash = 0, lkeys = 0, lsplit = 1;
   float* d_Up = nullptr;                    // derived: recurrent kernels in the recurrence kernels' register order, [enc][layer][dir][65536]
   float* d_Wp = nullptr;                    // derived: input kernels of encoder layers >= 1 as MFMA B fragments, [enc][layer-1][dir][131072]
+  uint16_t* d_Wsb = nullptr;                // derived: the same kernels cut into three bf16 parts, [enc][layer-1][dir][32 tiles][3 parts][8 k-steps][64 lanes][8]
+  uint16_t* d_Wh = nullptr;                 // derived: ... as two f16 parts of the column-scaled kernels + 512 column factors, [enc][layer-1][dir][RV_WH_SLOT]
+  int opt_split_proj = 2;                   // fused projection on split-bf16 MFMAs (six part products, f32-equivalent); 0 = f32 MFMAs
   int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
   float* d_Wmp = nullptr;                   // derived: [W_mem | A_c] [256][256] (A_c = W_att rows 128..383): projection of the attention memory for the persistent decode
   float* d_Wcat2 = nullptr;                 // derived (one decoder cell): [W_a ; U + A_h W_a] [256][512]
   float* d_Nh = nullptr;                    // derived (one decoder cell): A_h W_fc [128][V]
+  uint16_t* d_Wmp16 = nullptr;              // derived: Wmp as two f16 parts in MFMA fragment order + column factors (launch_gemm_mem_split)
   float* mem2 = nullptr;                    // [B,Tm,256] = enc_out . Wmp: keys | attention-layer image of the values
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
   const float *W_mem = nullptr, *W_q = nullptr, *v_att = nullptr, *W_att = nullptr, *W_fc = nullptr, *b_fc = nullptr;
@@ -88,7 +92,8 @@ struct RvContext {
   int *d_clen = nullptr, *pin_clen = nullptr;
 
   int opt_taps = 0, opt_graph = 1, opt_profile = 0;
-  long long* rec_ts = nullptr;              // diagnostic: per-wave cycle sums of the raw layer-0 recurrence (RV_REC_STAMPS)
+  long long* rec_ts = nullptr;              // diagnostic: per-wave cycle sums of the raw layer-0 recurrence (RV_REC_STAMPS=1) or of its fused layer 1 (=2)
+  int rec_ts_layer = 0;
   int opt_ptaps = 0, lptaps = 0;            // persist_taps: per-step logits of the persistent decode (debug)
   std::map<std::string, ProfEntry> prof;
   struct Pending { std::string name; hipEvent_t a, b; };
@@ -124,6 +129,18 @@ int dalloc(RvContext* h, T** p, size_t count) {
   h->allocs.push_back(q);
   *p = static_cast<T*>(q);
   return RV_OK;
+}
+
+#define RV_WH_SLOT ((size_t)2 * RV_E * RV_G + 2 * RV_G)   // uint16 per (encoder, layer, direction) of d_Wh
+// bf16 with round-to-nearest-even, and back (finite inputs: the weights)
+inline uint16_t bf16_rne(float x) {
+  uint32_t u; memcpy(&u, &x, 4);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_value(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float x; memcpy(&x, &u, 4);
+  return x;
 }
 
 size_t weight_count(const RvConfig& c) {
@@ -242,7 +259,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
       Scope sc(h, e == 0 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0", s);
       a.tail_wave = h->opt_tail_wave;
-      a.dbg_ts = e == 0 ? h->rec_ts : nullptr;
+      a.dbg_ts = (e == 0 && h->rec_ts_layer == 0) ? h->rec_ts : nullptr;
       launch_lstm_rec(a, F, bt, s);
       a.dbg_ts = nullptr;
     } else {
@@ -252,8 +269,11 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         a.dbg_role = h->dbg_role;
         for (int dr = 0; dr < 2; ++dr) {
           a.Wp[dr] = h->d_Wp + ((size_t)(e * (depth - 1) + (l - 1)) * 2 + dr) * RV_E * RV_G;
+          a.Wh[dr] = h->opt_split_proj == 2 ? h->d_Wh + ((size_t)(e * (depth - 1) + (l - 1)) * 2 + dr) * RV_WH_SLOT : nullptr;
+          a.Wsb[dr] = h->opt_split_proj == 1 ? h->d_Wsb + ((size_t)(e * (depth - 1) + (l - 1)) * 2 + dr) * 3 * RV_E * RV_G : nullptr;
           a.bias[dr] = h->enc[e][l][dr].b;
         }
+        a.dbg_ts = (e == 0 && l == 1 && h->rec_ts_layer == 1) ? h->rec_ts : nullptr;
         Scope sc(h, e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p", s);
         launch_lstm_rec_proj(a, bt, s);
         continue;
@@ -477,7 +497,8 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
       g.M = B * Tm; g.N = RV_E; g.K = RV_E;
       g.xcd_remap = 1;
       Scope sc(h, "gemm_memory");
-      launch_gemm_f32(g, false, s);
+      if (h->opt_split_proj) launch_gemm_mem_split(h->enc_out, B * Tm, h->d_Wmp16, h->mem2, s);
+      else launch_gemm_f32(g, false, s);
     }
     d.values = h->mem2; part[0].values = h->mem2;
     Scope sc(h, "dec_persist", nullptr, true);
@@ -596,10 +617,13 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
+  TRY(dalloc(h, &h->d_Wmp16, RV_WMP16_SLOT));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wh, (size_t)2 * (c.enc_depth - 1) * 2 * RV_WH_SLOT));
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wsb, (size_t)2 * (c.enc_depth - 1) * 2 * 3 * RV_E * RV_G));
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
@@ -620,7 +644,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
   DecState& d = h->dec_st;
   if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
-  if (getenv("RV_REC_STAMPS")) TRY(dalloc(h, &h->rec_ts, 24));
+  if (getenv("RV_REC_STAMPS")) { TRY(dalloc(h, &h->rec_ts, 24)); h->rec_ts_layer = atoi(getenv("RV_REC_STAMPS")) == 2 ? 1 : 0; }
   if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
   d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
   TRY(dalloc(h, &d.xh, c.dec_depth * N * RV_E));
@@ -730,6 +754,45 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
                   t[(((size_t)nt * 16 + g) * 64 + ln) * 4 + i] = blob[off + (size_t)(16 * g + 4 * i + (ln >> 4)) * RV_G + 16 * nt + (ln & 15)];
           float* dst = h->d_Wp + ((size_t)(e * (h->cfg.enc_depth - 1) + (l - 1)) * 2 + dr) * RV_E * RV_G;
           HIPCHK(h, hipMemcpy(dst, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+          // ... and as bf16 parts: lane (kq = lane/16, col = lane%16) of tile nt, k-step ks holds W[32 ks + 8 kq + j][16 nt + col], j = 0..7
+          std::vector<uint16_t> sb((size_t)3 * RV_E * RV_G);
+          for (int nt = 0; nt < 32; ++nt)
+            for (int ks = 0; ks < 8; ++ks)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                  float r = blob[off + (size_t)(32 * ks + 8 * (ln >> 4) + j) * RV_G + 16 * nt + (ln & 15)];
+                  for (int part = 0; part < 3; ++part) {
+                    const uint16_t b = bf16_rne(r);
+                    sb[((((size_t)nt * 3 + part) * 8 + ks) * 64 + ln) * 8 + j] = b;
+                    r -= bf16_value(b);                    // exact
+                  }
+                }
+          // ... and as two f16 parts of s_n W (s_n: power of two, column maximum into [2^13, 2^14]), then the factors 2^-14 / s_n
+          std::vector<uint16_t> wh(RV_WH_SLOT);
+          float cs[RV_G];
+          for (int n = 0; n < RV_G; ++n) {
+            float mx = 0.f;
+            for (int k = 0; k < RV_E; ++k) mx = std::max(mx, std::fabs(blob[off + (size_t)k * RV_G + n]));
+            int ex = 0;
+            if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);     // mx = m 2^ex, m in [0.5, 1)
+            cs[n] = std::ldexp(1.0f, 14 - ex);                           // s_n; mx s_n in [2^13, 2^14)
+          }
+          for (int nt = 0; nt < 32; ++nt)
+            for (int ks = 0; ks < 8; ++ks)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                  const int n = 16 * nt + (ln & 15);
+                  const float v = blob[off + (size_t)(32 * ks + 8 * (ln >> 4) + j) * RV_G + n] * cs[n];   // exact
+                  const _Float16 hi = (_Float16)v;
+                  const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
+                  uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                  wh[((((size_t)nt * 2 + 0) * 8 + ks) * 64 + ln) * 8 + j] = hb;
+                  wh[((((size_t)nt * 2 + 1) * 8 + ks) * 64 + ln) * 8 + j] = lb;
+                }
+          for (int n = 0; n < RV_G; ++n) { const float f = std::ldexp(1.0f, -14) / cs[n]; memcpy(&wh[(size_t)2 * RV_E * RV_G + 2 * n], &f, 4); }
+          HIPCHK(h, hipMemcpy(h->d_Wh + ((size_t)(e * (h->cfg.enc_depth - 1) + (l - 1)) * 2 + dr) * RV_WH_SLOT, wh.data(), wh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+          uint16_t* dsb = h->d_Wsb + ((size_t)(e * (h->cfg.enc_depth - 1) + (l - 1)) * 2 + dr) * 3 * RV_E * RV_G;
+          HIPCHK(h, hipMemcpy(dsb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
     {   // [W_mem | A_c] [256][256]: column block 0 = W_mem (keys), column block 1 = rows 128..383 of the attention layer
         // (its context part), so that enc_out . Wmp = [keys | image of the values under the attention layer]
@@ -741,6 +804,29 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           wmp[(size_t)kk * RV_E + RV_U + n] = blob[ao + (size_t)kk * RV_U + n];
         }
       HIPCHK(h, hipMemcpy(h->d_Wmp, wmp.data(), wmp.size() * sizeof(float), hipMemcpyHostToDevice));
+      std::vector<uint16_t> img(RV_WMP16_SLOT);
+      float cs[RV_E];
+      for (int n = 0; n < RV_E; ++n) {
+        float mx = 0.f;
+        for (int kk = 0; kk < RV_E; ++kk) mx = std::max(mx, std::fabs(wmp[(size_t)kk * RV_E + n]));
+        int ex = 0;
+        if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);
+        cs[n] = std::ldexp(1.0f, 14 - ex);
+      }
+      for (int ks = 0; ks < 8; ++ks)
+        for (int nt = 0; nt < 16; ++nt)
+          for (int ln = 0; ln < 64; ++ln)
+            for (int j = 0; j < 8; ++j) {
+              const int n = 16 * nt + (ln & 15);
+              const float v = wmp[(size_t)(32 * ks + 8 * (ln >> 4) + j) * RV_E + n] * cs[n];
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+              img[((((size_t)ks * 16 + nt) * 2 + 0) * 64 + ln) * 8 + j] = hb;
+              img[((((size_t)ks * 16 + nt) * 2 + 1) * 64 + ln) * 8 + j] = lb;
+            }
+      for (int n = 0; n < RV_E; ++n) { const float f = std::ldexp(1.0f, -14) / cs[n]; memcpy(&img[(size_t)2 * RV_E * RV_E + 2 * n], &f, 4); }
+      HIPCHK(h, hipMemcpy(h->d_Wmp16, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (h->cfg.dec_depth == 1) {
       // attention = h . A_h + ctx'; its h part is folded into what consumes the attention vector (products in double):
@@ -809,6 +895,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
+  else if (!strcmp(key, "split_projection")) h->opt_split_proj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");
     h->opt_att_nt = value;

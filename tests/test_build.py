@@ -18,7 +18,8 @@ LIMITS = {
     r"k_dec_persistILi5ELi11ELi1ELi0E": 64,      # C3: Luong, beam 5, T_m <= 352 (36 B today)
     r"k_dec_persistILi5ELi8ELi1ELi0E": 0,        # R: T_m <= 256
     r"k_dec_persistILi5ELi11ELi1ELi1E": 64,      # C3 with Bahdanau (28 B today)
-    r"k_lstm_rec_projILi2EE": 0,                 # C3 fused recurrence + projection
+    r"k_lstm_rec_projILi2ELi[012]EE": 0,         # C3 fused recurrence + projection (f32, split-bf16 and split-f16 MFMA forms)
+    r"k_gemm_mem_split": 0,                      # attention-memory projection on split-f16 MFMAs
     r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
     r"k_lstm_rec_twILi2ELi1EE": 0, r"k_lstm_rec_twILi2ELi5EE": 0,   # C3 layer 0 (tail-wave variant)
 }
@@ -27,7 +28,7 @@ LIMITS = {
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_hot_kernels_do_not_spill(tmp_path):
     found = {}
-    for src, extra in (("decode.hip", []), ("lstm_rec.hip", ["-fno-slp-vectorize"])):
+    for src, extra in (("decode.hip", []), ("lstm_rec.hip", ["-fno-slp-vectorize"]), ("gemm_f32.hip", [])):
         out = tmp_path / (src + ".s")
         subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra,
                         os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)

@@ -2,7 +2,7 @@
 barriers (wait), per step.  Waves 0-7 = packed-FMA waves, 8-11 = cell-update waves.  Needs the -DRV_REC_STAMPS build:
   make -C ravvent-basecaller_amd/csrc stamps && RAVVENT_HIP_LIB=ravvent-basecaller_amd/csrc/libravvent_hip_stamps.so python tools/rec_stamps.py [B]"""
 import os, sys
-os.environ["RV_REC_STAMPS"] = "1"
+os.environ.setdefault("RV_REC_STAMPS", "1")      # 2 = the fused layer-1 kernel (waves 0-7 recurrence, 8-11 projection)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ravvent_basecaller_amd as rv
@@ -13,6 +13,10 @@ bc.init_random_weights(seed=22)
 raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=0)
 x = (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
 for _ in range(5):
+    bc.beam_search_prediction(x, W, L)
+ts = bc.get_tensor("rec_stamps").reshape(12, 2)
+if len(sys.argv) > 2: bc.set_option("split_projection", int(sys.argv[2]))
+for _ in range(2):
     bc.beam_search_prediction(x, W, L)
 ts = bc.get_tensor("rec_stamps").reshape(12, 2)
 print(f"B={B} T={T_r}: per wave (busy, barrier wait) cycles per step:")
