@@ -128,6 +128,10 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.
  *                       The step_ids / parent_ids / step_scores taps of a chunk then end at its own last
  *                       step instead of the slab's),
+ *          "matrix_attention" (0/1, default 1: the persistent decode with Luong attention and one decoder cell takes its scores
+ *                       and its context on the matrix pipe -- the chunk's keys and attention-layer image stay resident as f16
+ *                       MFMA fragments, two parts per value, three exact part products per block as in "split_projection";
+ *                       0 = packed fp32 FMAs on fp32 rows.  Results agree to f32 rounding),
  *          "persist_taps" (0/1, default 0: the persistent decode also records every step's logits [S,B,W,V] for
  *                       rv_get_tensor("step_logits"); rows of a chunk beyond its own last step ("chunk_steps") are not written),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around

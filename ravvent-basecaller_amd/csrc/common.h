@@ -108,6 +108,10 @@ struct DecState {
   uint8_t lut[RV_MAX_VOCAB];   // token id -> upper-case letter, 0 for tokens the string form drops
   int* chunk_steps;       // persistent decode: [B] steps each chunk ran (nullptr on the per-step graph path)
   int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
+  // persistent decode, Luong, one cell: scores and context as split-f16 MFMAs.  Scales: powers of two that bring the largest
+  // value a key / a U' element can take (from the weights; |enc_out| <= 1) into [2^13, 2^14); descale = 2^-14 / scale (the query
+  // and the alignments are scaled by 2^14)
+  int mx_attention; float mx_kscale, mx_kdescale, mx_uscale, mx_udescale;
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

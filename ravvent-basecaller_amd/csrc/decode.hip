@@ -150,6 +150,19 @@ __global__ __launch_bounds__(512) void k_dec_cell(DecState d, int layer, const f
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// 8 floats -> two f16 fragments of v * scale: hi = f16(s), lo = f16(s - hi) (the residual is exact in f32)
+__device__ __forceinline__ void split_f16x8(const float* v, float scale, float4& hi, float4& lo) {
+  h8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float sv = v[j] * scale;
+    a[j] = (_Float16)sv;
+    b[j] = (_Float16)(sv - (float)a[j]);
+  }
+  hi = __builtin_bit_cast(float4, a); lo = __builtin_bit_cast(float4, b);
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
@@ -907,8 +920,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
                                                       const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1,
                                                       const float* __restrict__ Nh /*D == 1: A_h . W_fc [128,V]*/) {
   constexpr int NT = 512;
+  constexpr bool BAH = ATT == 1;           // Bahdanau scores on the VALU
+  constexpr bool MX = ATT == 2;            // Luong attention (scores and context) on the matrix pipe, split-f16 operands
+  static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
   extern __shared__ __align__(16) float dsm[];
-  const PersistLds L(W, D, ATT);
+  const PersistLds L(W, D, BAH);
   float* pqs = dsm + L.pq;  float* vat = dsm + L.vat;   // ATT == 1 only
   constexpr bool CACHE = persist_weight_cache(W, D);
   float* wcache = dsm + L.wcache;                        // CACHE only: rows 72 g + 104 + i of Wcat at [(8 g + i) * 512], g = 0..2
@@ -933,9 +949,39 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   //      pass over the registers scores two rows.  U' (the context side): every lane 8 columns of each of the stream's rows.
   constexpr int NP = (NIT + 1) / 2;
   const int half = sub >> 3, s8 = sub & 7;
-  float4 kr[NP][4], ur[NIT][2];
+  float4 kr[MX ? 1 : NP][4], ur[MX ? 1 : NIT][2];
+  // MX: the same memory as MFMA B fragments (v_mfma_f32_16x16x32_f16), two f16 parts of the scaled values each.  Scores: wave
+  // wv owns the 16-step tiles wv + 8 c; lane (n = step l % 16 of the tile, kq = l / 16) holds key[t][32 ks + 8 kq + 0..7].
+  // Context: wave wv owns units 16 wv .. 16 wv + 15; lane (n = unit, kq) holds U'[32 ks + 8 kq + 0..7][unit].  The scales are
+  // powers of two from the weights (|key| <= sum_k |W_mem[k][u]| because |enc_out| <= 1): nothing can overflow f16, and what
+  // falls into its subnormals is below 2^-28 of the largest value the column can take.
+  constexpr int NTT = (2 * NIT + 7) / 8;
+  float4 kb[MX ? NTT : 1][4][2], ub[MX ? NIT : 1][2];
   unsigned livebits = 0;
-  {
+  if constexpr (MX) {
+    const float* cbase = d.values + (size_t)b * Tm * RV_E;
+    const uint8_t* mrow = d.mask + (size_t)b * Tm;
+    const int l16 = lane & 15, kq = lane >> 4, wv0 = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < NTT; ++c) {
+      const int t = 16 * (wv0 + 8 * c) + l16, tc = min(t, Tm - 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(cbase + (size_t)tc * RV_E + 32 * ks + 8 * kq);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(cbase + (size_t)tc * RV_E + 32 * ks + 8 * kq + 4);
+        split_f16x8(v, d.mx_kscale, kb[c][ks][0], kb[c][ks][1]);
+      }
+      if (t < Tm && mrow[tc]) livebits |= 1u << c;          // _maybe_mask_score: padded steps never score
+    }
+#pragma unroll
+    for (int ks = 0; ks < NIT; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = cbase[(size_t)min(32 * ks + 8 * kq + j, Tm - 1) * RV_E + RV_U + 16 * wv0 + l16];
+      split_f16x8(v, d.mx_uscale, ub[ks][0], ub[ks][1]);
+    }
+  } else {
     const float* cbase = d.values + (size_t)b * Tm * RV_E;
     const uint8_t* mrow = d.mask + (size_t)b * Tm;
 #pragma unroll
@@ -945,7 +991,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         kr[p][m] = *reinterpret_cast<const float4*>(q + 4 * m);
-        if (ATT) {   // Bahdanau: tanh(k + pq) = 1 - 2 / (1 + exp2((k + pq) * 2 log2 e)): the keys carry the factor from here on
+        if (BAH) {   // Bahdanau: tanh(k + pq) = 1 - 2 / (1 + exp2((k + pq) * 2 log2 e)): the keys carry the factor from here on
           kr[p][m].x *= 2.0f * LOG2E; kr[p][m].y *= 2.0f * LOG2E; kr[p][m].z *= 2.0f * LOG2E; kr[p][m].w *= 2.0f * LOG2E;
         }
       }
@@ -983,7 +1029,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           *reinterpret_cast<const float4*>(Wcat + (size_t)(72 * (r >> 3) + 104 + (r & 7)) * RV_G + 4 * c);
     }
   }
-  if (ATT && tid < RV_U) vat[tid] = d.v_att[tid] * (-2.0f * LOG2E);   // score = sum_j v_j tanh(.) = const - 2 sum_j v_j / (1 + exp(.)): softmax drops the constant
+  if (BAH && tid < RV_U) vat[tid] = d.v_att[tid] * (-2.0f * LOG2E);   // score = sum_j v_j tanh(.) = const - 2 sum_j v_j / (1 + exp(.)): softmax drops the constant
   if (tid < WB) {
     s_tok[tid] = d.start_token; s_lprob[tid] = tid == 0 ? 0.f : -INFINITY;
     s_fin[tid] = 0; s_len[tid] = 0; s_parent[tid] = tid;
@@ -1020,7 +1066,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wq + (size_t)u * RV_U);
     };
-    if (ATT) wq_prefetch();
+    if (BAH) wq_prefetch();
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
       const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
@@ -1034,6 +1080,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
       if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
+      if constexpr (MX) {      // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
+        const float sv = (hh * LOG2E) * 16384.f;
+        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+        _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 8 + w) * 8 + (u & 7);
+        qa[0] = hi; qa[1024] = lo;
+      }
     }
     __syncthreads();
     if (D > 1) {
@@ -1086,7 +1138,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       __syncthreads();
     }
-    if (ATT) {
+    if (BAH) {
       // ================= Bahdanau: processed query pq = h . W_q (BahdanauAttention.query_layer, no bias); thread = (4 columns,
       //   1 of 16 K groups of 8 rows), partial sums through `part` (free between the gates and the context phase)
       const int d4 = tid & 31, kg = tid >> 5;
@@ -1143,6 +1195,112 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     RV_STAMP(d, step, 3);
 
+    if constexpr (MX) {
+      // ================= scores on the matrix pipe: rows = beams (16-row tile, rows >= W unused: a row of A only feeds its own
+      //   row of C, so whatever those rows of the LDS image hold is harmless), columns = the 16 steps of a tile, K = 128 units.
+      //   C/D map: lane l holds column l % 16, rows 4 (l / 16) + i: beams 0-3 in lanes 0-15, beams 4-7 in lanes 16-31.
+      const int l16 = lane & 15, kq = lane >> 4;
+      float sc[NTT][4];
+      {
+        const _Float16* qa = reinterpret_cast<const _Float16*>(fold) + (kq * 8 + (l16 & 7)) * 8;
+        f4v acc[NTT];
+#pragma unroll
+        for (int c = 0; c < NTT; ++c) acc[c] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                    // one k-step of the query at a time: 8 registers of A fragments live
+          const h8 ah = *reinterpret_cast<const h8*>(qa + ks * 256), al = *reinterpret_cast<const h8*>(qa + 1024 + ks * 256);
+#pragma unroll
+          for (int c = 0; c < NTT; ++c) {
+            const h8 bh = __builtin_bit_cast(h8, kb[c][ks][0]), bl = __builtin_bit_cast(h8, kb[c][ks][1]);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < NTT; ++c) {
+          const bool live = (livebits >> c) & 1u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sc[c][i] = (live && lane < 32 && 4 * kq + i < W) ? acc[c][i] * d.mx_kdescale : -INFINITY;
+        }
+      }
+      RV_STAMP(d, step, 4);
+      // ================= softmax over the chunk's T_m steps: per-wave (max, sum) of every beam, one fixed-order merge
+      //   (raw v_exp_f32: arguments <= 0, a result below 2^-126 is an alignment of 0 either way)
+      float mrow_[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float m = sc[0][i];
+#pragma unroll
+        for (int c = 1; c < NTT; ++c) m = fmaxf(m, sc[c][i]);
+        m = fmaxf(m, dpp<0xB1>(m)); m = fmaxf(m, dpp<0x4E>(m)); m = fmaxf(m, dpp<0x141>(m)); m = fmaxf(m, dpp<0x140>(m));
+        const float ms = m == -INFINITY ? 0.f : m;           // a wave without live steps for this beam: every term exp2(-inf) = 0
+        float lsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NTT; ++c) { sc[c][i] = __builtin_amdgcn_exp2f(sc[c][i] - ms); lsum += sc[c][i]; }
+        lsum = row16_sum(lsum);
+        mrow_[i] = m;
+        if (l16 == 0 && lane < 32) { ml[wv * WB + 4 * kq + i] = m; ml[(8 + wv) * WB + 4 * kq + i] = lsum; }
+      }
+      __syncthreads();
+      {
+        // merge: lane (beam = lane / 8, wave g = lane % 8) takes one (max, sum) pair; 8-lane butterflies give every lane of the
+        // group the beam's maximum and its total (the same instruction sequence in every wave: the same bits in every wave)
+        const float mv = ml[(lane & 7) * WB + (lane >> 3)], lv = ml[(8 + (lane & 7)) * WB + (lane >> 3)];
+        float Mgl = mv;
+        Mgl = fmaxf(Mgl, dpp<0xB1>(Mgl)); Mgl = fmaxf(Mgl, dpp<0x4E>(Mgl)); Mgl = fmaxf(Mgl, dpp<0x141>(Mgl));
+        float tl = mv == -INFINITY ? 0.f : lv * __builtin_amdgcn_exp2f(mv - Mgl);
+        tl += dpp<0xB1>(tl); tl += dpp<0x4E>(tl); tl += dpp<0x141>(tl);
+        // all-masked chunk: 0 / 0 = NaN like the reference
+        const float rt = Mgl == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tl;
+        const int Mi = __float_as_int(Mgl), Ri = __float_as_int(rt);
+        // alignments -> A fragments of the context product: [part][k-block t / 8][row beam][t % 8] f16 of alpha 2^14 (in `part`,
+        // idle between the gates and the cell product at the end of the step)
+        _Float16* aa = reinterpret_cast<_Float16*>(part);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float Mg = __int_as_float((kq & 1) ? __builtin_amdgcn_readlane(Mi, 8 * (4 + i)) : __builtin_amdgcn_readlane(Mi, 8 * i));
+          const float rr = __int_as_float((kq & 1) ? __builtin_amdgcn_readlane(Ri, 8 * (4 + i)) : __builtin_amdgcn_readlane(Ri, 8 * i));
+          const bool nanrow = rr != rr && 4 * kq + i < W;
+          const float f = (4 * kq + i >= W || mrow_[i] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mrow_[i] - Mg) * rr * 16384.f;
+#pragma unroll
+          for (int c = 0; c < NTT; ++c) {
+            const int t = 16 * (wv + 8 * c) + l16;
+            if (lane < 32 && t < 32 * NIT) {
+              const float av = nanrow ? rr : sc[c][i] * f;
+              const _Float16 hi = (_Float16)av, lo = (_Float16)(av - (float)hi);
+              _Float16* q = aa + ((t >> 3) * 8 + 4 * kq + i) * 8 + (t & 7);
+              q[0] = hi; q[NIT * 256] = lo;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      RV_STAMP(d, step, 5);
+      // ================= attention-layer context part = sum_t alpha_t U'_t on the matrix pipe: rows = beams, this wave's 16 units,
+      //   K = the chunk's steps; the product is complete in one wave (no partial sums to merge)
+      {
+        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 8 + (l16 & 7)) * 8;
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NIT; ++ks) {
+          const h8 ah = *reinterpret_cast<const h8*>(aa + ks * 256), al = *reinterpret_cast<const h8*>(aa + NIT * 256 + ks * 256);
+          const h8 bh = __builtin_bit_cast(h8, ub[ks][0]), bl = __builtin_bit_cast(h8, ub[ks][1]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        }
+        RV_STAMP(d, step, 6);
+        if (lane < 32) {
+          const int col = 16 * wv + l16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * kq + i < W) { const float av = acc[i] * d.mx_udescale; att[(4 * kq + i) * RV_U + col] = av; attT[col * WB + 4 * kq + i] = av; }
+        }
+      }
+      __syncthreads();
+    } else {
     // ================= scores from the resident key rows: lane w keeps beam w's score of the even row of a pair, lane 8 + w
     //   that of the odd row
     float sc[NP];
@@ -1152,11 +1310,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     for (int w = 0; w < W; ++w) {
       float4 qv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&(ATT ? pqs : qp)[w * RV_U + 16 * s8 + 4 * m]);
+      for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&(BAH ? pqs : qp)[w * RV_U + 16 * s8 + 4 * m]);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         f2 pp = f2{0.f, 0.f};
-        if (ATT) {
+        if (BAH) {
           // Bahdanau, normalize = False: score_t = sum_j v_j tanh(keys_tj + pq_j); keys and pq carry 2 log2(e),
           // v carries -2 log2(e): score * log2(e) = const + sum_j v'_j / (1 + exp2(k'_tj + pq'_j)), the constant cancels in the softmax.
           // Raw v_exp_f32 (no denormal-range rescue: 1 + e does not see it; +inf gives rcp = 0 = tanh's limit)
@@ -1260,6 +1418,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       att[i] = av; attT[col * WB + w] = av;
     }
     __syncthreads();
+    }
     RV_STAMP(d, step, 8);
     // ================= logits = attention . W_fc + b_fc: 8 lanes per output, all W*V <= 35 outputs in one pass
     {
@@ -1533,7 +1692,7 @@ __global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
 template <int W, int D, int ATT>
 static void launch_persist_wd(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                               const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
-  const size_t shm = sizeof(float) * PersistLds(W, D, ATT).total;
+  const size_t shm = sizeof(float) * PersistLds(W, D, ATT == 1).total;
   if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
   else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
   else hipLaunchKernelGGL((k_dec_persist<W, 11, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
@@ -1545,6 +1704,7 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
     if (d.depth > 1) { launch_persist_wd<W, 2, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
   if (d.attention == 1) launch_persist_wd<W, 1, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);     // Bahdanau: one decoder cell
+  else if (d.mx_attention) launch_persist_wd<W, 1, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);  // Luong, scores and context on the matrix pipe
   else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
@@ -1640,6 +1800,9 @@ static hipError_t configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 1>), sizeof(float) * PersistLds(W, 1, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
   if constexpr (W <= 5) {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);

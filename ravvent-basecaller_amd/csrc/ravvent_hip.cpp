@@ -60,6 +60,8 @@ struct RvContext {
   uint16_t* d_Wsb = nullptr;                // derived: the same kernels cut into three bf16 parts, [enc][layer-1][dir][32 tiles][3 parts][8 k-steps][64 lanes][8]
   uint16_t* d_Wh = nullptr;                 // derived: ... as two f16 parts of the column-scaled kernels + 512 column factors, [enc][layer-1][dir][RV_WH_SLOT]
   int opt_split_proj = 2;                   // fused projection on split-bf16 MFMAs (six part products, f32-equivalent); 0 = f32 MFMAs
+  int opt_mx_att = 1;                       // persistent decode (Luong, one cell): attention on the matrix pipe
+  float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
   int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
@@ -501,6 +503,9 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
       else launch_gemm_f32(g, false, s);
     }
     d.values = h->mem2; part[0].values = h->mem2;
+    d.mx_attention = (h->opt_mx_att && c.attention == RV_ATT_LUONG && d.depth == 1) ? 1 : 0;
+    d.mx_kscale = h->mx_kscale; d.mx_kdescale = std::ldexp(1.0f, -14) / h->mx_kscale;
+    d.mx_uscale = h->mx_uscale; d.mx_udescale = std::ldexp(1.0f, -14) / h->mx_uscale;
     Scope sc(h, "dec_persist", nullptr, true);
     launch_dec_persist(d, d.depth > 1 ? h->dec[0].W + (size_t)V * RV_G : h->d_Wcat2, h->dec[0].W, h->dec[0].b,
                        d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, h->d_Nh, s);
@@ -804,6 +809,16 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           wmp[(size_t)kk * RV_E + RV_U + n] = blob[ao + (size_t)kk * RV_U + n];
         }
       HIPCHK(h, hipMemcpy(h->d_Wmp, wmp.data(), wmp.size() * sizeof(float), hipMemcpyHostToDevice));
+      {   // |enc_out| <= 1, so |key_tu| <= sum_k |W_mem[k][u]| and |U'_tn| <= sum_k |A_c[k][n]|: the largest column sums bound both
+        double bk = 0.0, bu = 0.0;
+        for (int n = 0; n < RV_E; ++n) {
+          double cs = 0.0;
+          for (int kk = 0; kk < RV_E; ++kk) cs += std::fabs((double)wmp[(size_t)kk * RV_E + n]);
+          if (n < RV_U) bk = std::max(bk, cs); else bu = std::max(bu, cs);
+        }
+        auto pow2_scale = [](double bound) { int ex = 0; if (bound > 0.0 && std::isfinite(bound)) std::frexp(bound * 1.0001, &ex); return std::ldexp(1.0f, 14 - ex); };
+        h->mx_kscale = pow2_scale(bk); h->mx_uscale = pow2_scale(bu);
+      }
       std::vector<uint16_t> img(RV_WMP16_SLOT);
       float cs[RV_E];
       for (int n = 0; n < RV_E; ++n) {
@@ -895,6 +910,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
+  else if (!strcmp(key, "matrix_attention")) h->opt_mx_att = value != 0;
   else if (!strcmp(key, "split_projection")) h->opt_split_proj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");

@@ -369,7 +369,7 @@ def test_every_documented_option_is_accepted(rv):
     doc = hdr[hdr.index("/* Options:"):hdr.index("int rv_set_option")]
     keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
     assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
-            "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "profile"} <= keys
+            "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "matrix_attention", "profile"} <= keys
     bc, _ = _mk(rv)
     for k in sorted(keys):
         bc.set_option(k, 1 if k != "attend_threads" else 256)
