@@ -1196,13 +1196,17 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     RV_STAMP(d, step, 3);
 
     if constexpr (MX) {
-      // ================= scores on the matrix pipe: rows = beams (16-row tile, rows >= W unused: a row of A only feeds its own
-      //   row of C, so whatever those rows of the LDS image hold is harmless), columns = the 16 steps of a tile, K = 128 units.
-      //   C/D map: lane l holds column l % 16, rows 4 (l / 16) + i: beams 0-3 in lanes 0-15, beams 4-7 in lanes 16-31.
+      // ================= scores on the matrix pipe: rows = beams, columns = the 16 steps of a tile, K = 128 units.
+      //   C/D map: lane l holds column l % 16 and rows 4 g + i (g = l / 16).  Beam w sits in row 4 (w % 4) + w / 4, so that
+      //   register i = 0 holds beams 0-3 (one per 16-lane group, all 64 lanes busy) and i = 1 beams 4-7: the softmax below
+      //   touches W <= 4 ? 1 : 2 registers per tile, not 4.  A row of A only feeds its own row of C, so the unused rows of the
+      //   16-row tile read whatever slot their index aliases to, harmlessly.  LDS images keep 8 row slots, slot = beam.
+      constexpr int NI = W > 4 ? 2 : 1;
       const int l16 = lane & 15, kq = lane >> 4;
-      float sc[NTT][4];
+      const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;    // the beam whose row this lane feeds as an A operand
+      float sc[NTT][NI];
       {
-        const _Float16* qa = reinterpret_cast<const _Float16*>(fold) + (kq * 8 + (l16 & 7)) * 8;
+        const _Float16* qa = reinterpret_cast<const _Float16*>(fold) + (kq * 8 + aslot) * 8;
         f4v acc[NTT];
 #pragma unroll
         for (int c = 0; c < NTT; ++c) acc[c] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -1222,15 +1226,15 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         for (int c = 0; c < NTT; ++c) {
           const bool live = (livebits >> c) & 1u;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) sc[c][i] = (live && lane < 32 && 4 * kq + i < W) ? acc[c][i] * d.mx_kdescale : -INFINITY;
+          for (int i = 0; i < NI; ++i) sc[c][i] = (live && kq + 4 * i < W) ? acc[c][i] * d.mx_kdescale : -INFINITY;
         }
       }
       RV_STAMP(d, step, 4);
       // ================= softmax over the chunk's T_m steps: per-wave (max, sum) of every beam, one fixed-order merge
       //   (raw v_exp_f32: arguments <= 0, a result below 2^-126 is an alignment of 0 either way)
-      float mrow_[4];
+      float mrow_[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         float m = sc[0][i];
 #pragma unroll
         for (int c = 1; c < NTT; ++c) m = fmaxf(m, sc[c][i]);
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         for (int c = 0; c < NTT; ++c) { sc[c][i] = __builtin_amdgcn_exp2f(sc[c][i] - ms); lsum += sc[c][i]; }
         lsum = row16_sum(lsum);
         mrow_[i] = m;
-        if (l16 == 0 && lane < 32) { ml[wv * WB + 4 * kq + i] = m; ml[(8 + wv) * WB + 4 * kq + i] = lsum; }
+        if (l16 == 0) { ml[wv * WB + kq + 4 * i] = m; ml[(8 + wv) * WB + kq + 4 * i] = lsum; }
       }
       __syncthreads();
       {
@@ -1254,23 +1258,23 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         tl += dpp<0xB1>(tl); tl += dpp<0x4E>(tl); tl += dpp<0x141>(tl);
         // all-masked chunk: 0 / 0 = NaN like the reference
         const float rt = Mgl == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tl;
-        const int Mi = __float_as_int(Mgl), Ri = __float_as_int(rt);
-        // alignments -> A fragments of the context product: [part][k-block t / 8][row beam][t % 8] f16 of alpha 2^14 (in `part`,
+        // alignments -> A fragments of the context product: [part][k-block t / 8][slot beam][t % 8] f16 of alpha 2^14 (in `part`,
         // idle between the gates and the cell product at the end of the step)
         _Float16* aa = reinterpret_cast<_Float16*>(part);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float Mg = __int_as_float((kq & 1) ? __builtin_amdgcn_readlane(Mi, 8 * (4 + i)) : __builtin_amdgcn_readlane(Mi, 8 * i));
-          const float rr = __int_as_float((kq & 1) ? __builtin_amdgcn_readlane(Ri, 8 * (4 + i)) : __builtin_amdgcn_readlane(Ri, 8 * i));
-          const bool nanrow = rr != rr && 4 * kq + i < W;
-          const float f = (4 * kq + i >= W || mrow_[i] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mrow_[i] - Mg) * rr * 16384.f;
+        for (int i = 0; i < NI; ++i) {
+          const int beam = kq + 4 * i;                         // its merged pair sits in lanes 8 beam .. 8 beam + 7
+          const float Mg = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * beam, __float_as_int(Mgl)));
+          const float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * beam, __float_as_int(rt)));
+          const bool nanrow = rr != rr && beam < W;
+          const float f = (beam >= W || mrow_[i] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mrow_[i] - Mg) * rr * 16384.f;
 #pragma unroll
           for (int c = 0; c < NTT; ++c) {
             const int t = 16 * (wv + 8 * c) + l16;
-            if (lane < 32 && t < 32 * NIT) {
+            if (t < 32 * NIT) {
               const float av = nanrow ? rr : sc[c][i] * f;
               const _Float16 hi = (_Float16)av, lo = (_Float16)(av - (float)hi);
-              _Float16* q = aa + ((t >> 3) * 8 + 4 * kq + i) * 8 + (t & 7);
+              _Float16* q = aa + ((t >> 3) * 8 + beam) * 8 + (t & 7);
               q[0] = hi; q[NIT * 256] = lo;
             }
           }
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       // ================= attention-layer context part = sum_t alpha_t U'_t on the matrix pipe: rows = beams, this wave's 16 units,
       //   K = the chunk's steps; the product is complete in one wave (no partial sums to merge)
       {
-        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 8 + (l16 & 7)) * 8;
+        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 8 + aslot) * 8;
         f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NIT; ++ks) {
@@ -1292,12 +1296,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
         }
         RV_STAMP(d, step, 6);
-        if (lane < 32) {
-          const int col = 16 * wv + l16;
+        const int col = 16 * wv + l16;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (4 * kq + i < W) { const float av = acc[i] * d.mx_udescale; att[(4 * kq + i) * RV_U + col] = av; attT[col * WB + 4 * kq + i] = av; }
-        }
+        for (int i = 0; i < NI; ++i)
+          if (kq + 4 * i < W) { const float av = acc[i] * d.mx_udescale; att[(kq + 4 * i) * RV_U + col] = av; attT[col * WB + kq + 4 * i] = av; }
       }
       __syncthreads();
     } else {
