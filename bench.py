@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 
 BASES_PER_CHUNK = 6
 PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_NOTE = ("fp32 matrix / vector peak, the arithmetic type the path computes in; its input projections and its Luong scores / context "
+             "take each fp32 product as three exact f16 part products on v_mfma_f32_16x16x32_f16 (2.5 PFLOP/s pipe), the recurrences, "
+             "the decoder cell and the softmax run packed fp32 FMAs: FLOPs counted are the algorithm's fp32 FLOPs, not MFMA operations")
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 DEC_FLOPS = lambda Tm: 369408 + 768 * Tm     # per beam row per decode step
 
@@ -355,6 +358,8 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "launches": n, "flops_per_launch": fl,
                     "flops_reference": fl_ref, "flops_executed": fl, "traffic": None}
         roof["share_of_slab_time"] = round(per_slab[name] / sum(per_slab.values()), 3)
+        if roof["bound"] == "mfma":
+            roof["peak_note"] = PEAK_NOTE
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
@@ -390,7 +395,8 @@ def main():
             "roofline_path": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
                               "frac": round(tf_exec / (PEAK_F32_TFLOPS * world), 4),
                               "flops_per_chunk_reference": path_ref, "flops_per_chunk_executed": round(path_exec),
-                              "achieved_reference": round(tf_ref, 2), "frac_reference": round(tf_ref / (PEAK_F32_TFLOPS * world), 4)},
+                              "achieved_reference": round(tf_ref, 2), "frac_reference": round(tf_ref / (PEAK_F32_TFLOPS * world), 4),
+                              "peak_note": PEAK_NOTE},
             "kernel_ms_per_slab": {k: round(v, 4) for k, v in sorted(per_slab.items())},
             "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
             "device_ms_per_step": round(total_ms / args.steps, 4),

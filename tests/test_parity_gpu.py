@@ -100,6 +100,47 @@ def test_beam_search_matches_oracle(rv, oracle, W):
     bc.close()
 
 
+@pytest.mark.parametrize("W,Tr,Te", [(2, 40, 9), (5, 200, 30), (7, 300, 45), (5, 300, 45), (1, 17, 3)])
+def test_matrix_attention_matches_fp32_rows_and_oracle(rv, oracle, W, Tr, Te):
+    """rv_set_option("matrix_attention"): scores and context of the persistent decode as split-f16 MFMAs on fragments resident in
+    registers (1, the default) against packed fp32 FMAs on fp32 rows (0): every step's logits within 2e-5 of each other and within
+    1e-4 of the fp64 oracle, tokens / beam ids / parents identical, at the three memory-length variants of the kernel
+    (T_m <= 64, <= 256, <= 352), with padded steps at both ends of the memory and weights scaled up (larger keys)."""
+    B, L = 7, 14
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=Tr, max_event_len=Te)
+    flat = rv.weights.init_weights(bc.cfg, seed=50 + W, gain=1.5)
+    flat["b_fc"][bc.cfg.end_token] = 0.3
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=W, max_raw_pad=min(15, Tr - 1), max_event_pad=min(10, Te - 1))
+    raw[2, Tr // 3:] = 0.0                        # a chunk with most of its raw steps padded
+    bc.set_option("persist_taps", 1)
+    bc.set_option("profile", 1)
+    got = {}
+    for mx in (1, 0):
+        bc.set_option("matrix_attention", mx)
+        tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+        assert "dec_persist" in bc.profile()
+        cs = bc.get_tensor("chunk_steps").astype(int)
+        S = tok.shape[1]
+        got[mx] = (tok.numpy().copy(), sc.numpy().copy(), cs, bc.get_tensor("step_logits").reshape(S, B, W, 7).copy(),
+                   bc.get_tensor("step_ids").reshape(S, B, W).copy(), bc.get_tensor("parent_ids").reshape(S, B, W).copy())
+    taps = {}
+    otok, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
+    for mx in (1, 0):
+        tok, sc, cs, lg, ids, par = got[mx]
+        assert tok.shape == otok.shape and (tok == otok).all() and np.abs(sc - osc).max() < TOL, mx
+        for b in range(B):
+            n = cs[b]
+            assert np.abs(lg[:n, b] - taps["step_logits"][:n, b]).max() < TOL, (mx, b)
+            assert (ids[:n, b] == taps["step_ids"][:n, b]).all() and (par[:n, b] == taps["parent_ids"][:n, b]).all(), (mx, b)
+    assert (got[1][2] == got[0][2]).all()
+    for b in range(B):
+        n = got[1][2][b]
+        assert np.abs(got[1][3][:n, b] - got[0][3][:n, b]).max() < 2e-5, b
+    bc.close()
+
+
 @pytest.mark.parametrize("W,dec_depth", [(1, 1), (5, 1), (8, 1), (3, 2)])
 def test_persistent_decode_step_logits(rv, oracle, W, dec_depth):
     """Tensor-level check of the DEFAULT product path in beam mode: the one-launch persistent decode records its

@@ -9,7 +9,7 @@ python3 - <<'PY'
 import csv, glob, collections, json, os
 root = os.environ["GRAFT_REPO_ROOT"]
 names = {"k_dec_persist": "dec_persist", "k_dec_attend_flash": "dec_attend", "k_dec_attend<": "dec_attend_two_pass", "k_dec_cell": "dec_cell",
-         "k_gemm_f32<2, 2": "gemm_memory", "k_lstm_rec_proj<2": "lstm_rec_l1p_fused", "k_lstm_rec<2, 0": "lstm_rec_l1p", "k_lstm_rec<2, 1": "lstm_rec_raw_l0", "k_lstm_rec_tw<2, 1": "lstm_rec_raw_l0",
+         "k_gemm_f32<2, 2": "gemm_memory", "k_gemm_mem_split": "gemm_memory", "k_lstm_rec_proj<2": "lstm_rec_l1p_fused", "k_lstm_rec<2, 0": "lstm_rec_l1p", "k_lstm_rec<2, 1": "lstm_rec_raw_l0", "k_lstm_rec_tw<2, 1": "lstm_rec_raw_l0",
          "k_lstm_rec_tw<2, 5": "lstm_rec_event_l0",
          "k_lstm_rec<2, 5": "lstm_rec_event_l0"}
 out = collections.defaultdict(lambda: {"fetch_kb": [], "write_kb": []})
