@@ -13,6 +13,7 @@
 // next tile's global loads held in registers across the MFMA phase.  A is stored k-major in LDS
 // (row pad 2 -> conflict-free ds_write_b32 of the transposed float4s, conflict-free operand reads).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -247,6 +248,109 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mem_split(const float* __restri
   }
 }
 
+
+// The same product with the two memory streams in different waves.  A wave's vector-memory counter retires in issue order, so a
+// wave that mixes the A rows (HBM, microseconds) with the B slabs (L2) waits for HBM every time it waits for a slab.  Here waves
+// 0-5 compute (16 rows each, 96-row tiles) and touch global memory only for A -- all 8 k-steps of a tile in one burst, the NEXT
+// tile's burst issued before the current tile's MFMAs, so HBM latency is off the critical path -- and waves 6-7 only move the B
+// slabs L2 -> registers -> LDS, one k-step ahead.  Persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are
+// raw s_barrier + lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.
+__global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
+                                                         float* __restrict__ C, int ntiles) {
+  __shared__ __align__(16) char Bs[2][32768];
+  __shared__ float css[RV_E];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+#define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+  if (wave >= 6) {                                         // ---------------- loader role
+    const int p = tid - 384;                               // 0..127: 16 float4 of every 32 KB slab
+    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
+    css[p] = cs[p]; css[p + 128] = cs[p + 128];
+    // (sixteen named registers: as an array carried around the loop the compiler keeps them in scratch)
+#define RV_ST16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define RV_DECL(i) float4 st##i;
+    RV_ST16(RV_DECL)
+#define RV_LD1(i) st##i = src_[128 * i];
+#define RV_ST1(i) dst_[128 * i] = st##i;
+#define RV_B_LD(ks_) do { \
+      const float4* src_ = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + (size_t)((ks_) & 7) * 32768) + p; \
+      RV_ST16(RV_LD1) } while (0)
+#define RV_B_ST(buf_) do { \
+      float4* dst_ = reinterpret_cast<float4*>(Bs[buf_]) + p; \
+      RV_ST16(RV_ST1) } while (0)
+    RV_B_LD(0); RV_B_ST(0); RV_B_LD(1);
+    RV_LDS_BARRIER();
+    for (int it = 0; it < 8 * nloc; ++it) {
+      RV_B_ST((it + 1) & 1);                               // slab it + 1 (read in iteration it + 1); that buffer was last read in it - 1
+      RV_B_LD(it + 2);
+      RV_LDS_BARRIER();
+    }
+    return;
+  }
+  // ---------------- compute role
+  const int l16 = lane & 15, q = lane >> 4;
+  float4 ac[8][2], an[8][2];
+#define RV_A_LOAD(tile_, dst_) do { \
+    const float* ap_ = A + (size_t)min((tile_) * 96 + 16 * wave + l16, M - 1) * RV_E + 8 * q; \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) { \
+      dst_[ks_][0] = *reinterpret_cast<const float4*>(ap_ + 32 * ks_); \
+      dst_[ks_][1] = *reinterpret_cast<const float4*>(ap_ + 32 * ks_ + 4); } } while (0)
+  RV_A_LOAD((int)blockIdx.x, ac);
+  RV_LDS_BARRIER();
+  for (int n = 0; n < nloc; ++n) {
+    const int tile = blockIdx.x + n * gridDim.x;
+    RV_A_LOAD(n + 1 < nloc ? tile + (int)gridDim.x : tile, an);      // (the last tile re-reads its own rows: L2 hits, dropped)
+    f4v acc[16];
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) acc[nt] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      h8 ah, al;
+      {
+        const float4 x0 = ac[ks][0], x1 = ac[ks][1];
+        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sv = v[j] * 16384.f;
+          ah[j] = (_Float16)sv;
+          al[j] = (_Float16)(sv - (float)ah[j]);
+        }
+      }
+      const char* bs = Bs[ks & 1] + lane * 16;             // 8 iterations per tile: the buffer parity of iteration 8 n + ks is ks & 1
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) {
+        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
+      }
+      RV_LDS_BARRIER();
+    }
+    const int rbase = tile * 96 + 16 * wave + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      const int col = 16 * nt + l16;
+      const float f = css[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rbase + i < M && rbase + i < tile * 96 + 96) C[(size_t)(rbase + i) * RV_E + col] = acc[nt][i] * f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { ac[ks][0] = an[ks][0]; ac[ks][1] = an[ks][1]; }
+  }
+#undef RV_LDS_BARRIER
+#undef RV_A_LOAD
+#undef RV_B_LD
+#undef RV_B_ST
+#undef RV_ST16
+#undef RV_DECL
+#undef RV_LD1
+#undef RV_ST1
+}
+
 void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
-  hipLaunchKernelGGL(k_gemm_mem_split, dim3((M + 127) / 128), dim3(256), 0, s, A, M, img, C);
+  static const bool one_role = getenv("RV_GEMM_ONE_ROLE") != nullptr;      // A/B timing of the first form
+  if (one_role) { hipLaunchKernelGGL(k_gemm_mem_split, dim3((M + 127) / 128), dim3(256), 0, s, A, M, img, C); return; }
+  const int ntiles = (M + 95) / 96;
+  hipLaunchKernelGGL(k_gemm_mem_split2, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, s, A, M, img, C, ntiles);
 }
