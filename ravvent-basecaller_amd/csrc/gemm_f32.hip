@@ -253,38 +253,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mem_split(const float* __restri
 // wave that mixes the A rows (HBM, microseconds) with the B slabs (L2) waits for HBM every time it waits for a slab.  Here waves
 // 0-5 compute (16 rows each, 96-row tiles) and touch global memory only for A -- all 8 k-steps of a tile in one burst, the NEXT
 // tile's burst issued before the current tile's MFMAs, so HBM latency is off the critical path -- and waves 6-7 only move the B
-// slabs L2 -> registers -> LDS, one k-step ahead.  Persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are
+// slabs L2 -> LDS (LDS-DMA, three buffers), two k-steps ahead.  Persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are
 // raw s_barrier + lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.
 __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
                                                          float* __restrict__ C, int ntiles) {
-  __shared__ __align__(16) char Bs[2][32768];
+  __shared__ __align__(16) char Bs[3][32768];
   __shared__ float css[RV_E];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
 #define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
   if (wave >= 6) {                                         // ---------------- loader role
-    const int p = tid - 384;                               // 0..127: 16 float4 of every 32 KB slab
+    const int p = tid - 384;                               // 0..127
     const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
     css[p] = cs[p]; css[p + 128] = cs[p + 128];
-    // (sixteen named registers: as an array carried around the loop the compiler keeps them in scratch)
-#define RV_ST16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-#define RV_DECL(i) float4 st##i;
-    RV_ST16(RV_DECL)
-#define RV_LD1(i) st##i = src_[128 * i];
-#define RV_ST1(i) dst_[128 * i] = st##i;
-#define RV_B_LD(ks_) do { \
-      const float4* src_ = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + (size_t)((ks_) & 7) * 32768) + p; \
-      RV_ST16(RV_LD1) } while (0)
-#define RV_B_ST(buf_) do { \
-      float4* dst_ = reinterpret_cast<float4*>(Bs[buf_]) + p; \
-      RV_ST16(RV_ST1) } while (0)
-    RV_B_LD(0); RV_B_ST(0); RV_B_LD(1);
+    // slab -> LDS by LDS-DMA (16 x 1 KB per wave, no staging registers, no ds_write): thread p moves bytes [16 p + 2048 i, +16);
+    // a wave instruction lands 1 KB at its wave-uniform base + 16 lane.  Three buffers: slab it + 2 is requested at the start
+    // of iteration it (its buffer was last read in it - 1), slab it + 1 must have landed at its end: vmcnt(16) = all but
+    // the youngest batch.
+    auto dma = [&](int slab) {
+      const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab & 7) * 32768 + p * 16;
+      char* dst = Bs[slab % 3] + (wave - 6) * 1024;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2048 * i),
+                                         (__attribute__((address_space(3))) void*)(dst + 2048 * i), 16, 0, 0);
+    };
+    dma(0); dma(1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     RV_LDS_BARRIER();
     for (int it = 0; it < 8 * nloc; ++it) {
-      RV_B_ST((it + 1) & 1);                               // slab it + 1 (read in iteration it + 1); that buffer was last read in it - 1
-      RV_B_LD(it + 2);
+      dma(it + 2);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       RV_LDS_BARRIER();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
   // ---------------- compute role
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
           al[j] = (_Float16)(sv - (float)ah[j]);
         }
       }
-      const char* bs = Bs[ks & 1] + lane * 16;             // 8 iterations per tile: the buffer parity of iteration 8 n + ks is ks & 1
+      const char* bs = Bs[(8 * n + ks) % 3] + lane * 16;
 #pragma unroll
       for (int nt = 0; nt < 16; ++nt) {
         const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
@@ -340,12 +342,7 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
   }
 #undef RV_LDS_BARRIER
 #undef RV_A_LOAD
-#undef RV_B_LD
-#undef RV_B_ST
-#undef RV_ST16
-#undef RV_DECL
-#undef RV_LD1
-#undef RV_ST1
+
 }
 
 void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
