@@ -223,3 +223,40 @@ def test_bench_self_launch_command(monkeypatch):
     # executed-FLOP accounting of the decode: chunk_steps replace B * S
     assert bench.algorithmic_flops("dec_persist", 4, 300, 30, 5, 47) == 4 * 5 * 47 * (369408 + 768 * 330)
     assert bench.algorithmic_flops("dec_persist", 4, 300, 30, 5, 47, [47, 10, 12, 47]) == 5 * 116 * (369408 + 768 * 330)
+
+
+def test_split_f16_operands_hold_fp32_products():
+    """The arithmetic behind `split_projection` / `matrix_attention` ("split operands"), restated in numpy: a
+    value scaled below 2^14 and cut as v = f16(v) + f16(v - f16(v)) is held to 2^-23 of itself, every f16 x f16 part product is exact
+    in f32, and x.w = xh.wh + xh.wl + xl.wh is no further from the fp64 product than an f32 FMA chain over the same operands."""
+    rng = np.random.default_rng(5)
+    M, K, N = 256, 256, 64
+    x = (np.tanh(rng.normal(0, 0.7, (M, K))) * rng.uniform(0, 1, (M, K))).astype(np.float32)       # |x| <= 1, like an LSTM output
+    w = rng.uniform(-0.09, 0.09, (K, N)).astype(np.float32)
+    w[:, :4] *= 30.0; w[:, 4:8] *= 1e-3; w[7, 20] = 4.0                                              # large / tiny columns, an outlier
+    sx = np.float32(2.0 ** 14)
+    sw = (2.0 ** (14 - np.ceil(np.log2(np.abs(w).max(axis=0) * 1.0001)))).astype(np.float32)        # power of two per column
+
+    def split(v):
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        return hi, lo
+
+    xs, ws = x * sx, w * sw
+    assert np.abs(xs).max() < 65504 and np.abs(ws).max() < 65504 and np.abs(ws).max(axis=0).min() >= 2.0 ** 13 / 1.0001
+    xh, xl = split(xs); wh, wl = split(ws)
+    for v, h, l in ((xs, xh, xl), (ws, wh, wl)):
+        err = np.abs(v.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
+        big = np.abs(v) >= 2.0 ** -3                      # (below that the low part reaches the f16 subnormals: 2^-25 absolute, 2^-39 of the 2^14 range)
+        assert (err[big] <= np.abs(v[big]) * 2.0 ** -22).all() and (err[~big] <= 2.0 ** -25).all()
+    # part products are exact in f32: 11-bit x 11-bit significands
+    p32 = xh[:, :1].astype(np.float32) * wh[:1, :].astype(np.float32)
+    assert (p32.astype(np.float64) == xh[:, :1].astype(np.float64) * wh[:1, :].astype(np.float64)).all()
+    d = lambda a, b: a.astype(np.float64) @ b.astype(np.float64)
+    got = ((d(xh, wh) + d(xh, wl) + d(xl, wh)) / (np.float64(sx) * sw.astype(np.float64))).astype(np.float32)
+    ref = d(x, w)
+    chain = np.zeros((M, N), np.float32)
+    for k in range(K):
+        chain = chain + x[:, k:k + 1] * w[k:k + 1, :]
+    e_split, e_chain = np.abs(got - ref), np.abs(chain - ref)
+    assert e_split.max() <= e_chain.max() and e_split.mean() <= e_chain.mean()
