@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mem_split(const float* __restri
 // slabs L2 -> LDS (LDS-DMA, three buffers), two k-steps ahead.  Persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are
 // raw s_barrier + lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.
 __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
-                                                         float* __restrict__ C, int ntiles) {
+                                                         float* __restrict__ C, int ntiles, int dbg) {
   __shared__ __align__(16) char Bs[3][32768];
   __shared__ float css[RV_E];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
   RV_LDS_BARRIER();
   for (int n = 0; n < nloc; ++n) {
     const int tile = blockIdx.x + n * gridDim.x;
-    RV_A_LOAD(n + 1 < nloc ? tile + (int)gridDim.x : tile, an);      // (the last tile re-reads its own rows: L2 hits, dropped)
+    if (!(dbg & 2)) RV_A_LOAD(n + 1 < nloc ? tile + (int)gridDim.x : tile, an);      // (the last tile re-reads its own rows: L2 hits, dropped)
     f4v acc[16];
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) acc[nt] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
 #pragma unroll
       for (int nt = 0; nt < 16; ++nt) {
         const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
+        if (dbg & 4) continue;
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
       const float f = css[col];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (rbase + i < M && rbase + i < tile * 96 + 96) C[(size_t)(rbase + i) * RV_E + col] = acc[nt][i] * f;
+        if (rbase + i < M && rbase + i < tile * 96 + 96 && !(dbg & 1)) C[(size_t)(rbase + i) * RV_E + col] = acc[nt][i] * f;
     }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { ac[ks][0] = an[ks][0]; ac[ks][1] = an[ks][1]; }
@@ -345,9 +346,119 @@ __global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict
 
 }
 
+
+// Third form: 4 compute waves of 32 rows (two 16-row tiles per B fragment read: half the LDS reads per MFMA of the 16-row waves
+// above, one compute wave per SIMD) + 2 loader waves; 128-row tiles, persistent.  The (tile, k-step) pairs of a workgroup form one
+// flat stream: the A floats of stream position it + 2 are requested while position it is multiplied, across tile boundaries too.
+__global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
+                                                         float* __restrict__ C, int ntiles, int dbg) {
+  __shared__ __align__(16) char Bs[3][32768];
+  __shared__ __align__(16) float css[RV_E];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+#define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+  if (wave >= 4) {                                         // ---------------- loader role (as in k_gemm_mem_split2)
+    const int p = tid - 256;                               // 0..127
+    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
+    css[p] = cs[p]; css[p + 128] = cs[p + 128];
+    auto dma = [&](int slab) {
+      const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab & 7) * 32768 + p * 16;
+      char* dst = Bs[slab % 3] + (wave - 4) * 1024;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2048 * i),
+                                         (__attribute__((address_space(3))) void*)(dst + 2048 * i), 16, 0, 0);
+    };
+    dma(0); dma(1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    RV_LDS_BARRIER();
+    for (int it = 0; it < 8 * nloc; ++it) {
+      dma(it + 2);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      RV_LDS_BARRIER();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // ---------------- compute role
+  const int l16 = lane & 15, q = lane >> 4;
+  float4 a0[2][2], a1[2][2];                               // A floats of the even / odd stream positions in flight ([row tile][half])
+#define RV_A_LOAD(tile_, ks_, dst_) do { \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) { \
+      const float* ap_ = A + (size_t)min((tile_) * 128 + 32 * wave + 16 * m_ + l16, M - 1) * RV_E + 8 * q + 32 * (ks_); \
+      dst_[m_][0] = *reinterpret_cast<const float4*>(ap_); dst_[m_][1] = *reinterpret_cast<const float4*>(ap_ + 4); } } while (0)
+  RV_A_LOAD((int)blockIdx.x, 0, a0);
+  RV_A_LOAD((int)blockIdx.x, 1, a1);
+  RV_LDS_BARRIER();
+  for (int n = 0; n < nloc; ++n) {
+    const int tile = blockIdx.x + n * gridDim.x;
+    const int tnext = n + 1 < nloc ? tile + (int)gridDim.x : tile;      // (the last tile re-reads two of its own k-steps: L2 hits, dropped)
+    f4v acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      h8 ah[2], al[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float4 x0 = (ks & 1) ? a1[m][0] : a0[m][0], x1 = (ks & 1) ? a1[m][1] : a0[m][1];
+        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sv = v[j] * 16384.f;
+          ah[m][j] = (_Float16)sv;
+          al[m][j] = (_Float16)(sv - (float)ah[m][j]);
+        }
+      }
+      if (!(dbg & 2)) {                                    // stream position + 2, into the registers just consumed
+        if (ks & 1) RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a1); else RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a0);
+      }
+      const char* bs = Bs[(8 * n + ks) % 3] + lane * 16;
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) {
+        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
+        if (dbg & 4) continue;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // operands swapped: the tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of this row tile), so a
+          // lane ends up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][nt], 0, 0, 0);
+        }
+      }
+      RV_LDS_BARRIER();
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int row = tile * 128 + 32 * wave + 16 * m + l16;      // C/D map of the transposed tile: column = lane % 16 = row of C,
+      if (row < M && !(dbg & 1)) {                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+          const float4 f = *reinterpret_cast<const float4*>(&css[16 * nt + 4 * q]);
+          *reinterpret_cast<float4*>(&C[(size_t)row * RV_E + 16 * nt + 4 * q]) =
+              make_float4(acc[m][nt][0] * f.x, acc[m][nt][1] * f.y, acc[m][nt][2] * f.z, acc[m][nt][3] * f.w);
+        }
+      }
+    }
+  }
+#undef RV_LDS_BARRIER
+#undef RV_A_LOAD
+}
+
 void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
   static const bool one_role = getenv("RV_GEMM_ONE_ROLE") != nullptr;      // A/B timing of the first form
   if (one_role) { hipLaunchKernelGGL(k_gemm_mem_split, dim3((M + 127) / 128), dim3(256), 0, s, A, M, img, C); return; }
+  static const bool six_waves = getenv("RV_GEMM_SIX_COMPUTE") != nullptr;   // A/B timing of the second form
+  if (!six_waves) {
+    const int nt128 = (M + 127) / 128;
+    static const int dbg3 = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
+    hipLaunchKernelGGL(k_gemm_mem_split3, dim3(nt128 < 256 ? nt128 : 256), dim3(384), 0, s, A, M, img, C, nt128, dbg3);
+    return;
+  }
   const int ntiles = (M + 95) / 96;
-  hipLaunchKernelGGL(k_gemm_mem_split2, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, s, A, M, img, C, ntiles);
+  static const int dbg = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;   // timing probes only (results invalid)
+  hipLaunchKernelGGL(k_gemm_mem_split2, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, s, A, M, img, C, ntiles, dbg);
 }

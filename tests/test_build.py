@@ -21,7 +21,7 @@ LIMITS = {
     r"k_dec_persistILi5ELi11ELi1ELi2E": 128,     # C3 with the attention on the matrix pipe (100 B today: six fragments parked in the prologue)
     r"k_dec_persistILi5ELi8ELi1ELi2E": 0,        # R
     r"k_lstm_rec_projILi2ELi[012]EE": 0,         # C3 fused recurrence + projection (f32, split-bf16 and split-f16 MFMA forms)
-    r"k_gemm_mem_split2": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
+    r"k_gemm_mem_split3": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
     r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
     r"k_lstm_rec_twILi2ELi1EE": 0, r"k_lstm_rec_twILi2ELi5EE": 0,   # C3 layer 0 (tail-wave variant)
 }
