@@ -143,6 +143,9 @@ int rv_set_option(rv_handle h, const char* key, int32_t value);
  *   "enc_output" [B,T_m,2u]   _encode_input's output              basecaller.py:405
  *   "mask"       [B,T_m]      input_mask (1.0 / 0.0)              basecaller.py:406
  *   "keys"       [B,T_m,d]    attention keys after setup_memory   basecaller.py:303
+ *   "projected_memory" [B,T_m,2u] enc_output . [W_mem | A_c]: keys (columns 0..u-1) and the attention layer's image of the values
+ *                              (A_c = rows u..3u-1 of the attention layer), what the persistent decode keeps on chip (last call
+ *                              must have run the persistent decode)
  *   "step_logits"     [S,B,W,V]   (needs debug_taps, or persist_taps on the persistent decode)
  *   "chunk_steps"     [B]         steps each chunk ran in the persistent decode (its beams all finished there)
  *   "step_alignments" [S,B,W,T_m] (needs debug_taps)

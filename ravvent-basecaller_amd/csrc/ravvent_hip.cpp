@@ -933,6 +933,10 @@ int rv_get_tensor(rv_handle h, const char* name, float* dst, size_t dst_floats, 
     if (!h->lkeys) return fail(h, RV_ESTATE, "keys were not built by the last call (single-pass attend); set debug_taps=1");
     src = h->keys; n = B * Tm * RV_U;
   }
+  else if (!strcmp(name, "projected_memory")) {
+    if (!h->lpersist) return fail(h, RV_ESTATE, "the projected memory is built for the persistent decode only (the last call ran the per-step kernels)");
+    src = h->mem2; n = B * Tm * RV_E;
+  }
   else if (!strcmp(name, "rec_stamps")) {
     if (!h->rec_ts) return fail(h, RV_ESTATE, "set RV_REC_STAMPS=1 before rv_create (and load a -DRV_REC_STAMPS build)");
     long long ts[24];

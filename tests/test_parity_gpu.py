@@ -100,6 +100,29 @@ def test_beam_search_matches_oracle(rv, oracle, W):
     bc.close()
 
 
+@pytest.mark.parametrize("B,Tr,Te", [(3, 40, 9), (130, 300, 30), (257, 100, 11)])
+def test_memory_projection_split_gemm_against_fp64(rv, B, Tr, Te):
+    """The attention-memory projection enc_output . [W_mem | A_c] (tap "projected_memory") on split-f16 MFMAs (default) and on f32 MFMAs
+    (split_projection = 0), each against the fp64 product of the tapped enc_output with the weights: the split form is no further
+    from fp64 than the f32 MFMA GEMM (x 1.5 + 1e-6), row counts that are not multiples of the 128-row tile included."""
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=Tr, max_event_len=Te)
+    flat = rv.weights.init_weights(bc.cfg, seed=9, gain=2.0)
+    flat["W_mem"][:, 5] *= 25.0; flat["W_att"][128 + 7, 3] = 6.0      # a large key column, an outlier in A_c
+    bc.set_weights_flat(flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=B, max_raw_pad=min(15, Tr - 1), max_event_pad=min(10, Te - 1))
+    wmp = np.concatenate([flat["W_mem"], flat["W_att"][128:384]], axis=1).astype(np.float64)       # [256, 256]
+    err = {}
+    for split in (2, 0):
+        bc.set_option("split_projection", split)
+        bc.beam_search_prediction((raw, ev), 3, 5)
+        enc = bc.get_tensor("enc_output").reshape(B, -1, 256).astype(np.float64)
+        got = bc.get_tensor("projected_memory").reshape(B, -1, 256)
+        err[split] = float(np.abs(got - enc @ wmp).max())
+    print("max |projected_memory - fp64|:", err)
+    assert err[0] < 1e-4 and err[2] <= 1.5 * err[0] + 1e-6, err
+    bc.close()
+
+
 @pytest.mark.parametrize("W,Tr,Te", [(2, 40, 9), (5, 200, 30), (7, 300, 45), (5, 300, 45), (1, 17, 3)])
 def test_matrix_attention_matches_fp32_rows_and_oracle(rv, oracle, W, Tr, Te):
     """rv_set_option("matrix_attention"): scores and context of the persistent decode as split-f16 MFMAs on fragments resident in
