@@ -38,7 +38,9 @@ void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s)
 // layers >= 1 with x . W + b computed inside the kernel (MFMA waves beside the recurrence waves): a.x = [B,T,256] activations,
 // a.Wp / a.bias per direction
 void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
-hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the fused-projection kernels; first error or hipSuccess
+hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the recurrence kernels; first error or hipSuccess
+// layer 0 stages its chunks' whole input windows in LDS: does a window of T steps x F features fit with that many rows per workgroup?
+bool lstm_rec_window_fits(int F, int rows_per_block, int T);
 
 // ---------------------------------------------------------------- K0/K2: fp32 MFMA GEMM
 struct GemmArgs {

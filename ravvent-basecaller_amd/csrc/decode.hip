@@ -878,6 +878,10 @@ __global__ __launch_bounds__(NT) void k_dec_attend_flash(DecState d, const float
 // Luong attention; beam search with W <= 8 (W <= 5 with two stacked cells: LDS) and greedy search.
 // one decoder cell and W <= 5 leave 48 KB of LDS: 24 of the 256 weight rows the cell product streams from L2 every step stay on chip
 __host__ __device__ constexpr bool persist_weight_cache(int W, int D) { return D == 1 && W <= 5; }
+constexpr int PERSIST_MAX_NIT = 11;      // resident row groups of 32 steps: T_m <= 352
+// `part` also holds the matrix-pipe attention's alignment image (two f16 parts of [32 NIT steps][8 beam slots] = NIT * 256 floats):
+// with one beam that image is larger than the partial sums, so the block is sized for the larger of the two
+__host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PERSIST_MAX_NIT * 256 ? 4 * W * RV_G : PERSIST_MAX_NIT * 256; }
 struct PersistLds {
   int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, wcache, total;
   __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
@@ -886,7 +890,7 @@ struct PersistLds {
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
     qp = o; o += W * RV_U;             // h * log2(e): the score query
-    part = o; o += 4 * W * RV_G;       // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
+    part = o; o += part_floats(W);     // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
                                        // layer's h-part partial sums [16][W][128] (after the gates -> merge)
     ctxp = part;                       // context partial sums of the 8 waves [8][W][128]: one cell -> inside `part` (idle between
     if (D > 1) { ctxp = o; o += 8 * W * RV_U; }   // the gates and the end of the step); two cells -> own space (`part` holds h . A_h then)
@@ -923,6 +927,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr bool BAH = ATT == 1;           // Bahdanau scores on the VALU
   constexpr bool MX = ATT == 2;            // Luong attention (scores and context) on the matrix pipe, split-f16 operands
   static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
+  static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= part_floats(W), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
+  static_assert(2 * 1024 * sizeof(_Float16) /* query image: 2 parts x [16 k-blocks][8 slots][8] f16 */ <= (8 * 4 * 2 * 16 * 4) * sizeof(float), "the query image must fit `fold`");
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D, BAH);
   float* pqs = dsm + L.pq;  float* vat = dsm + L.vat;   // ATT == 1 only

@@ -163,201 +163,33 @@ void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s) {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 2) void k_gemm_mem_split(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
-                                                           float* __restrict__ C) {
-  __shared__ __align__(16) char Bs[2][32768];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * 128 + 32 * wave;
-  const int q = lane >> 4;
-  const float* arow[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) arow[m] = A + (size_t)min(r0 + 16 * m + (lane & 15), M - 1) * RV_E + 8 * q;
-
-  f4v acc[2][16];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int nt = 0; nt < 16; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
-
-  float4 bst[4];                                           // half of the next B slab on its way to LDS
-  auto b_load = [&](int ks, int half) {
-    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + (size_t)ks * 32768 + half * 16384) + tid;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bst[i] = src[256 * i];
-  };
-  auto b_store = [&](int buf, int half) {
-    float4* dst = reinterpret_cast<float4*>(Bs[buf] + half * 16384) + tid;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[256 * i] = bst[i];
-  };
-  float4 ar[2][2];                                         // the next k-step's A floats
-  auto a_load = [&](int ks) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      ar[m][0] = *reinterpret_cast<const float4*>(arow[m] + 32 * ks);
-      ar[m][1] = *reinterpret_cast<const float4*>(arow[m] + 32 * ks + 4);
-    }
-  };
-  b_load(0, 0); b_store(0, 0); b_load(0, 1); b_store(0, 1); a_load(0);
-  __syncthreads();
-  for (int ks = 0; ks < 8; ++ks) {
-    h8 ah[2], al[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const float v[8] = {ar[m][0].x, ar[m][0].y, ar[m][0].z, ar[m][0].w, ar[m][1].x, ar[m][1].y, ar[m][1].z, ar[m][1].w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float s = v[j] * 16384.f;
-        ah[m][j] = (_Float16)s;
-        al[m][j] = (_Float16)(s - (float)ah[m][j]);        // exact residual, then one rounding
-      }
-    }
-    const bool more = ks + 1 < 8;
-    if (more) { b_load(ks + 1, 0); a_load(ks + 1); }
-    const char* bs = Bs[ks & 1] + lane * 16;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-      for (int nt = 8 * hf; nt < 8 * hf + 8; ++nt) {
-        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][nt], 0, 0, 0);
-        }
-      }
-      // the other buffer was last read in step ks - 1, which every wave left through the barrier below
-      if (more) { b_store((ks + 1) & 1, hf); if (hf == 0) b_load(ks + 1, 1); }
-    }
-    __syncthreads();
-  }
-  // C/D map of the 16x16 tile: col = lane % 16, row = 4 (lane / 16) + i; the column factors 2^-14 / s_n follow the image
-  const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
-#pragma unroll
-  for (int nt = 0; nt < 16; ++nt) {
-    const int col = 16 * nt + (lane & 15);
-    const float f = cs[col];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = r0 + 16 * m + 4 * q + i;
-        if (row < M) C[(size_t)row * RV_E + col] = acc[m][nt][i] * f;
-      }
-  }
-}
-
-
-// The same product with the two memory streams in different waves.  A wave's vector-memory counter retires in issue order, so a
-// wave that mixes the A rows (HBM, microseconds) with the B slabs (L2) waits for HBM every time it waits for a slab.  Here waves
-// 0-5 compute (16 rows each, 96-row tiles) and touch global memory only for A -- all 8 k-steps of a tile in one burst, the NEXT
-// tile's burst issued before the current tile's MFMAs, so HBM latency is off the critical path -- and waves 6-7 only move the B
-// slabs L2 -> LDS (LDS-DMA, three buffers), two k-steps ahead.  Persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are
-// raw s_barrier + lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.
-__global__ __launch_bounds__(512) void k_gemm_mem_split2(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
-                                                         float* __restrict__ C, int ntiles, int dbg) {
-  __shared__ __align__(16) char Bs[3][32768];
-  __shared__ float css[RV_E];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
-#define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-  if (wave >= 6) {                                         // ---------------- loader role
-    const int p = tid - 384;                               // 0..127
-    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
-    css[p] = cs[p]; css[p + 128] = cs[p + 128];
-    // slab -> LDS by LDS-DMA (16 x 1 KB per wave, no staging registers, no ds_write): thread p moves bytes [16 p + 2048 i, +16);
-    // a wave instruction lands 1 KB at its wave-uniform base + 16 lane.  Three buffers: slab it + 2 is requested at the start
-    // of iteration it (its buffer was last read in it - 1), slab it + 1 must have landed at its end: vmcnt(16) = all but
-    // the youngest batch.
-    auto dma = [&](int slab) {
-      const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab & 7) * 32768 + p * 16;
-      char* dst = Bs[slab % 3] + (wave - 6) * 1024;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2048 * i),
-                                         (__attribute__((address_space(3))) void*)(dst + 2048 * i), 16, 0, 0);
-    };
-    dma(0); dma(1);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    RV_LDS_BARRIER();
-    for (int it = 0; it < 8 * nloc; ++it) {
-      dma(it + 2);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      RV_LDS_BARRIER();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
-  // ---------------- compute role
-  const int l16 = lane & 15, q = lane >> 4;
-  float4 ac[8][2], an[8][2];
-#define RV_A_LOAD(tile_, dst_) do { \
-    const float* ap_ = A + (size_t)min((tile_) * 96 + 16 * wave + l16, M - 1) * RV_E + 8 * q; \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) { \
-      dst_[ks_][0] = *reinterpret_cast<const float4*>(ap_ + 32 * ks_); \
-      dst_[ks_][1] = *reinterpret_cast<const float4*>(ap_ + 32 * ks_ + 4); } } while (0)
-  RV_A_LOAD((int)blockIdx.x, ac);
-  RV_LDS_BARRIER();
-  for (int n = 0; n < nloc; ++n) {
-    const int tile = blockIdx.x + n * gridDim.x;
-    if (!(dbg & 2)) RV_A_LOAD(n + 1 < nloc ? tile + (int)gridDim.x : tile, an);      // (the last tile re-reads its own rows: L2 hits, dropped)
-    f4v acc[16];
-#pragma unroll
-    for (int nt = 0; nt < 16; ++nt) acc[nt] = f4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      h8 ah, al;
-      {
-        const float4 x0 = ac[ks][0], x1 = ac[ks][1];
-        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float sv = v[j] * 16384.f;
-          ah[j] = (_Float16)sv;
-          al[j] = (_Float16)(sv - (float)ah[j]);
-        }
-      }
-      const char* bs = Bs[(8 * n + ks) % 3] + lane * 16;
-#pragma unroll
-      for (int nt = 0; nt < 16; ++nt) {
-        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
-        if (dbg & 4) continue;
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
-      }
-      RV_LDS_BARRIER();
-    }
-    const int rbase = tile * 96 + 16 * wave + 4 * q;
-#pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
-      const int col = 16 * nt + l16;
-      const float f = css[col];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (rbase + i < M && rbase + i < tile * 96 + 96 && !(dbg & 1)) C[(size_t)(rbase + i) * RV_E + col] = acc[nt][i] * f;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { ac[ks][0] = an[ks][0]; ac[ks][1] = an[ks][1]; }
-  }
-#undef RV_LDS_BARRIER
-#undef RV_A_LOAD
-
-}
-
-
-// Third form: 4 compute waves of 32 rows (two 16-row tiles per B fragment read: half the LDS reads per MFMA of the 16-row waves
-// above, one compute wave per SIMD) + 2 loader waves; 128-row tiles, persistent.  The (tile, k-step) pairs of a workgroup form one
+// The kernel below is the third form of this product.  Measured on the way (C3 slab; both deleted from the tree after round 2, their
+// numbers are in DESIGN.md section 4): (1) one role -- every wave loads its A rows AND stages the B slabs: 0.084 ms, a wave's
+// vector-memory counter retires in issue order, so it waits for HBM at every slab hand-off; (2) six 16-row compute waves + two
+// loader waves, 96-row tiles: 0.065 ms, twice the LDS reads per MFMA of (3).
+// (3) The two memory streams live in different waves: 4 compute waves of 32 rows (two 16-row tiles per B fragment read, one compute
+// wave per SIMD) touch global memory only for A; 2 loader waves only move the B slabs L2 -> LDS (LDS-DMA, three buffers), two
+// k-steps ahead.  128-row tiles, persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are raw s_barrier +
+// lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.  The (tile, k-step) pairs of a workgroup form one
 // flat stream: the A floats of stream position it + 2 are requested while position it is multiplied, across tile boundaries too.
 __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
-                                                         float* __restrict__ C, int ntiles, int dbg) {
+                                                         float* __restrict__ C, int ntiles, int dbg_arg) {
+#ifdef RV_GEMM_DIAG    // timing probes (tools/gemm_probe.sh, `make gemm_diag`): 1 = no C stores, 2 = no A loads, 4 = no MFMAs; results invalid
+  const int dbg = dbg_arg;
+#else
+  constexpr int dbg = 0;
+  (void)dbg_arg;
+#endif
   __shared__ __align__(16) char Bs[3][32768];
   __shared__ __align__(16) float css[RV_E];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
 #define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-  if (wave >= 4) {                                         // ---------------- loader role (as in k_gemm_mem_split2)
+  if (wave >= 4) {                                         // ---------------- loader role
+    // slab -> LDS by LDS-DMA (16 x 1 KB per wave, no staging registers, no ds_write): thread p moves bytes [16 p + 2048 i, +16);
+    // a wave instruction lands 1 KB at its wave-uniform base + 16 lane.  Three buffers: slab it + 2 is requested at the start
+    // of iteration it (its buffer was last read in it - 1), slab it + 1 must have landed at its end: vmcnt(16) = all but
+    // the youngest batch.
     const int p = tid - 256;                               // 0..127
     const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
     css[p] = cs[p]; css[p + 128] = cs[p + 128];
@@ -449,16 +281,11 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
 }
 
 void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
-  static const bool one_role = getenv("RV_GEMM_ONE_ROLE") != nullptr;      // A/B timing of the first form
-  if (one_role) { hipLaunchKernelGGL(k_gemm_mem_split, dim3((M + 127) / 128), dim3(256), 0, s, A, M, img, C); return; }
-  static const bool six_waves = getenv("RV_GEMM_SIX_COMPUTE") != nullptr;   // A/B timing of the second form
-  if (!six_waves) {
-    const int nt128 = (M + 127) / 128;
-    static const int dbg3 = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
-    hipLaunchKernelGGL(k_gemm_mem_split3, dim3(nt128 < 256 ? nt128 : 256), dim3(384), 0, s, A, M, img, C, nt128, dbg3);
-    return;
-  }
-  const int ntiles = (M + 95) / 96;
-  static const int dbg = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;   // timing probes only (results invalid)
-  hipLaunchKernelGGL(k_gemm_mem_split2, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, s, A, M, img, C, ntiles, dbg);
+  const int nt128 = (M + 127) / 128;
+  int dbg = 0;
+#ifdef RV_GEMM_DIAG
+  static const int dbg_env = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
+  dbg = dbg_env;
+#endif
+  hipLaunchKernelGGL(k_gemm_mem_split3, dim3(nt128 < 256 ? nt128 : 256), dim3(384), 0, s, A, M, img, C, nt128, dbg);
 }

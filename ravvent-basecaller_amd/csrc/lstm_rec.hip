@@ -703,24 +703,27 @@ void launch_proj(const RecArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((k_lstm_rec_proj<BT, 0>), grid, dim3(768), proj_lds_bytes(BT, 0), s, a);
 }
 
+constexpr size_t REC_LDS_CAP = 160 * 1024;      // gfx950: 160 KB per workgroup (these kernels hold no static LDS)
+constexpr size_t one_lds_bytes(int bt, int F, int T) { return sizeof(float) * (2 * (size_t)bt * RV_U + (F > 0 ? (size_t)bt * T * F : 0)); }
+constexpr size_t tw_lds_bytes(int bt, int F, int T) { return sizeof(float) * ((size_t)bt * RV_U + (size_t)bt * RV_G + (size_t)bt * T * F); }
+
 template <int BT, int F>
 void launch_one(const RecArgs& a, hipStream_t s) {
   dim3 grid((a.B + BT - 1) / BT, 2);
-  size_t shm = sizeof(float) * (2 * BT * RV_U + (F > 0 ? (size_t)BT * a.T * F : 0));
-  hipLaunchKernelGGL((k_lstm_rec<BT, F>), grid, dim3(512), shm, s, a);
+  hipLaunchKernelGGL((k_lstm_rec<BT, F>), grid, dim3(512), one_lds_bytes(BT, F, a.T), s, a);
 }
 
 template <int BT, int F>
 void launch_tw(const RecArgs& a, hipStream_t s) {
   dim3 grid((a.B + BT - 1) / BT, 2);
-  const size_t shm = sizeof(float) * ((size_t)BT * RV_U + (size_t)BT * RV_G + (size_t)BT * a.T * F);
-  hipLaunchKernelGGL((k_lstm_rec_tw<BT, F>), grid, dim3(768), shm, s, a);
+  hipLaunchKernelGGL((k_lstm_rec_tw<BT, F>), grid, dim3(768), tw_lds_bytes(BT, F, a.T), s, a);
 }
 
 template <int F>
 void launch_f(const RecArgs& a, int bt, hipStream_t s) {
   if constexpr (F > 0) {
-    if (a.tail_wave && bt >= 2) {
+    // (the tail-wave form stages 12 KB more per 8 rows than the 8-wave form: very long windows fall back to the latter)
+    if (a.tail_wave && bt >= 2 && tw_lds_bytes(bt, F, a.T) <= REC_LDS_CAP) {
       switch (bt) {
         case 2: launch_tw<2, F>(a, s); return;
         case 4: launch_tw<4, F>(a, s); return;
@@ -746,9 +749,24 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s) {
     default: launch_proj<8>(a, s); break;
   }
 }
+bool lstm_rec_window_fits(int F, int rows_per_block, int T) {
+  return one_lds_bytes(rows_per_block, F, T) <= REC_LDS_CAP;     // launch_f falls back to the 8-wave form when the tail-wave form does not fit
+}
 hipError_t configure_rec_kernels() {
   const int shm = (int)proj_lds_bytes(8, 1);             // the largest of the three images
   hipError_t first = hipSuccess;
+  // layer-0 kernels stage the chunks' whole input windows: opt in to the full 160 KB (the 64 KB default is reached at
+  // T_event > 281 / T_raw > 1408 with 8 rows per workgroup)
+  for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec<1, 1>), reinterpret_cast<const void*>(&k_lstm_rec<2, 1>),
+                        reinterpret_cast<const void*>(&k_lstm_rec<4, 1>), reinterpret_cast<const void*>(&k_lstm_rec<8, 1>),
+                        reinterpret_cast<const void*>(&k_lstm_rec<1, 5>), reinterpret_cast<const void*>(&k_lstm_rec<2, 5>),
+                        reinterpret_cast<const void*>(&k_lstm_rec<4, 5>), reinterpret_cast<const void*>(&k_lstm_rec<8, 5>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_tw<2, 1>), reinterpret_cast<const void*>(&k_lstm_rec_tw<4, 1>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_tw<8, 1>), reinterpret_cast<const void*>(&k_lstm_rec_tw<2, 5>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_tw<4, 5>), reinterpret_cast<const void*>(&k_lstm_rec_tw<8, 5>)}) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)REC_LDS_CAP);
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  }
   for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_proj<1, 0>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2, 0>),
                         reinterpret_cast<const void*>(&k_lstm_rec_proj<4, 0>), reinterpret_cast<const void*>(&k_lstm_rec_proj<8, 0>),
                         reinterpret_cast<const void*>(&k_lstm_rec_proj<1, 1>), reinterpret_cast<const void*>(&k_lstm_rec_proj<2, 1>),

@@ -510,7 +510,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     launch_dec_persist(d, d.depth > 1 ? h->dec[0].W + (size_t)V * RV_G : h->d_Wcat2, h->dec[0].W, h->dec[0].b,
                        d.depth > 1 ? h->dec[1].W : nullptr, d.depth > 1 ? h->dec[1].b : nullptr, h->d_Nh, s);
   } else if (h->opt_graph && h->opt_profile != 2) {
-    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt, nsplit};
+    GraphKey key{B, d.W, Tm, L, greedy ? 1 : 0, h->opt_taps * 2 + h->lflash + 4 * h->opt_att_nt + 4096 * (d.step_logits ? 1 : 0), nsplit};   // every captured pointer that can change is in the key
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       if (h->graphs.size() >= 32) {      // bound the cache (callers with ever-changing slab shapes)
@@ -601,6 +601,13 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   for (int t : {c.start_token, c.end_token, c.pad_token})
     if (t < 0 || t >= c.vocab) return fail(nullptr, RV_EINVAL, "token id %d outside vocab", t);
 
+  {   // layer 0 keeps a workgroup's input windows in LDS (160 KB): reject maximum shapes no kernel variant can launch
+    const int bt = pick_rows_per_block(c.max_batch);
+    if (c.mode != RV_MODE_EVENT && !lstm_rec_window_fits(1, bt, c.max_raw_len))
+      return fail(nullptr, RV_EUNSUPPORTED, "max_raw_len %d with max_batch %d (%d chunks per workgroup) exceeds the 160 KB of LDS the layer-0 recurrence stages its input windows in", c.max_raw_len, c.max_batch, bt);
+    if (c.mode != RV_MODE_RAW && !lstm_rec_window_fits(5, bt, c.max_event_len))
+      return fail(nullptr, RV_EUNSUPPORTED, "max_event_len %d with max_batch %d (%d chunks per workgroup) exceeds the 160 KB of LDS the layer-0 recurrence stages its input windows in", c.max_event_len, c.max_batch, bt);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(nullptr, RV_EHIP, "no HIP device visible: libravvent_hip has no CPU path");

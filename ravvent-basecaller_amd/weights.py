@@ -157,3 +157,28 @@ def init_weights(cfg: RvConfig, seed: int = 22, scheme: str = "keras", gain: flo
             a = a * gain
         flat[name] = np.asarray(a, np.float32)
     return flat
+
+
+def base_calling_weights(cfg: RvConfig, seed: int = 1, gain: float = 3.0, token_gain: float = 6.0, recurrent_gain: float = 6.0,
+                         attention_gain: float = 4.0, forget_bias: float = -8.0, base_bias: float = 1.5,
+                         other_bias: float = -60.0) -> dict:
+    """Random weights whose best hypothesis is a full-length, VARIED base string.  The output bias favours a/c/g/t and pushes the
+    end, start and pad tokens out of reach, so every call has max_output_len - 1 letters and the read-level merger
+    (/root/reference/merger.py:155-248: 25-letter overlaps) really aligns, splices and appends.  The first decoder cell forgets
+    (negative forget bias) and its token rows, recurrent kernel and attention-input rows are scaled up: the cell is then a
+    chaotic map of (previous letter, attention, h), the letters change at ~3 of 4 steps, all four are used, and the calls differ
+    from chunk to chunk.  (Keras-default weights settle into homopolymer runs, on which the merger's local alignment finds nothing
+    and returns early, merger.py:181-197.)  Untrained weights cannot call a read CORRECTLY -- and a chaotic cell amplifies fp32
+    rounding, so these weights serve comparisons of the product with ITSELF (sharded == single-GPU == merged, byte for byte), not
+    comparisons against the oracle."""
+    flat = init_weights(cfg, seed=seed, gain=gain)
+    V, u = cfg.vocab, cfg.dec_units
+    flat["dec_cells.0.W"][:V] *= token_gain
+    flat["dec_cells.0.W"][V:] *= attention_gain
+    flat["dec_cells.0.U"] *= recurrent_gain
+    flat["dec_cells.0.b"][u:2 * u] = forget_bias
+    b = flat["b_fc"]
+    b[:] = base_bias
+    for t in (cfg.end_token, cfg.start_token, cfg.pad_token):
+        b[t] = other_bias
+    return flat

@@ -293,17 +293,39 @@ def _explain_mismatches(rv, oracle, bc, flat, mode, raw, ev, W, L, tok, ctok, ta
 
 # ----------------------------------------------------------------------------------------------
 # BASELINE.json full sizes against the C port of the oracle (numpy is too slow there)
+def _emitting_flat(rv, cfg, seed=22, end_bias=-1.0):
+    """Random weights biased to call bases (gain 3, base letters + 1.5, end token lowered): at Keras-default weights nearly every
+    best hypothesis at BASELINE sizes is a row of end tokens, and "tokens identical" is then nearly free."""
+    flat = rv.weights.init_weights(cfg, seed=seed, gain=3.0)
+    flat["b_fc"][3:7] += 1.5
+    flat["b_fc"][cfg.end_token] += end_bias
+    return flat
+
+
+def _assert_calls_are_strings(rv, bc, tok, tag):
+    """The compared rows are non-trivial: most best hypotheses hold several base letters and the calls differ between chunks."""
+    seqs = bc.tokens_to_nuc_sequences(tok)
+    lens = np.array([len(s) for s in seqs])
+    assert np.median(lens) >= 5 and len(set(seqs)) > 0.2 * len(seqs), (tag, np.median(lens), len(set(seqs)))
+    return lens
+
+
+@pytest.mark.parametrize("weights", ["keras", "emitting"])
 @pytest.mark.parametrize("B,T_r,T_e,W,L,tag", [
     (64, 300, 30, 1, 48, "C2"), (256, 300, 30, 5, 48, "C3"), (1024, 200, 30, 5, 32, "R"), (67, 123, 17, 4, 20, "ragged")])
-def test_full_size_against_c_port(rv, oracle, B, T_r, T_e, W, L, tag):
+def test_full_size_against_c_port(rv, oracle, B, T_r, T_e, W, L, tag, weights):
     from oracle import cpu_port
     bc, _ = _mk(rv, max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L)
-    flat = rv.weights.init_weights(bc.cfg, seed=22)
+    flat = rv.weights.init_weights(bc.cfg, seed=22) if weights == "keras" else _emitting_flat(rv, bc.cfg)
     bc.set_weights_flat(flat)
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=17)
     tok, sc = bc.beam_search_prediction((raw, ev), W, L)
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape, tag
+    tag = f"{tag}/{weights}"
+    if weights == "emitting":
+        lens = _assert_calls_are_strings(rv, bc, tok, tag)
+        print(f"{tag}: call lengths min / median / max {lens.min()} / {int(np.median(lens))} / {lens.max()}, {len(set(bc.tokens_to_nuc_sequences(tok)))} distinct calls")
     # fp32-vs-fp32 at 10^5 candidates: every row that differs must be explained by the fp64 oracle (100 % rows accounted for)
     same, n_bad = _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, tag, sc.numpy(), csc)
     print(f"{tag}: {n_bad} of {B} rows differ from the C port (tokens, or scores by >= 1e-4), all explained by the fp64 oracle")
@@ -597,22 +619,28 @@ def test_random_shapes_against_c_port(rv, oracle):
         bc.close()
 
 
+@pytest.mark.parametrize("weights", ["keras", "emitting"])
 @pytest.mark.parametrize("W", [5, 8, 1])
-def test_maximum_shapes_against_c_port(rv, oracle, W):
+def test_maximum_shapes_against_c_port(rv, oracle, W, weights):
     """The library's limits at once: T_raw + T_event = 352 (all 11 resident row groups of the persistent decode in use),
     max_output_len 64, beam 5 (persistent decode) / 8 (per-step kernels) / 1, a slab larger than the CU count."""
     from oracle import cpu_port
     B, T_r, T_e, L = 300, 307, 45, 64
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_r, max_event_len=T_e,
                        max_output_len=L)
-    flat = rv.weights.init_weights(bc.cfg, seed=41)
-    flat["b_fc"][bc.cfg.end_token] = 0.4 if W != 8 else 0.0
+    if weights == "keras":
+        flat = rv.weights.init_weights(bc.cfg, seed=41)
+        flat["b_fc"][bc.cfg.end_token] = 0.4 if W != 8 else 0.0
+    else:
+        flat = _emitting_flat(rv, bc.cfg, seed=41)
     bc.set_weights_flat(flat)
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=W)
     tok, sc = bc.beam_search_prediction((raw, ev), W, L)
     ctok, csc = cpu_port.run(bc.cfg.oracle_cfg(), 2, 7, rv.weights.pack(bc.cfg, flat), raw, ev, W, L)
     assert tok.shape == ctok.shape
-    _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, f"max shapes W={W}", sc.numpy(), csc)
+    if weights == "emitting":
+        _assert_calls_are_strings(rv, bc, tok, f"max shapes W={W}")
+    _explain_mismatches(rv, oracle, bc, flat, "joint", raw, ev, W, L, tok.numpy(), ctok, f"max shapes W={W}/{weights}", sc.numpy(), csc)
     with pytest.raises(rv._capi.RavventHipError):
         bc.beam_search_prediction((raw, ev), W, L + 1)
     bc.close()
