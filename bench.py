@@ -10,7 +10,10 @@ anything here touches the GPU), relays its JSON line and exits with its code; st
 
 A "step" is one pass of the hot path over one batch of synthetic chunks: workload C3 of BASELINE.json (joint
 raw+event mode, 300-sample raw windows + 30 events, beam 5, max_output_len 48), inputs resident in HBM before the
-timed region, outputs left in HBM.
+timed region, outputs left in HBM.  The K timed steps go through the library's asynchronous calls (rv_beam_search_submit_dev /
+rv_beam_search_collect_dev; `Basecaller.beam_search_stream`): --depth of them are in flight at a time, every step is collected
+inside the timed region, results are byte-identical to the synchronous call (`--depth 0` times that one instead, and its rate
+is reported beside the headline as `synchronous`).
   weak scaling (default): 256 chunks per GPU per step; with N > 1 the global slab of N x 256 chunks goes through the
     shipped multi-GPU path `dist.sharded_beam_search` (contiguous chunk shards, ONE RCCL all-gather per step).
   --strong: a fixed read of --read-chunks (8,192) chunks per step, sharded N ways, every rank decoding its shard
@@ -117,8 +120,9 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent
     """The reference's read-level metric (ravvent_performance_evaluator.py:79,86,125): bases_num / (t_predicting +
     t_postprocessing + t_merge) with bases_num = the read's REFERENCE length, through the evaluator call sequence on one
     synthetic long read (`synthetic.make_read`: ~8,200 chunks of <= 200 samples + <= 30 events, stride 6, cut by the
-    chunker), slabs of 1024 like the reference evaluator, fused on-device post-processing + C++ merger; weights biased to
-    emit bases (untrained weights cannot call the read correctly: `merged_bases` is reported, not scored).  Host buffers
+    chunker), slabs of 1024 like the reference evaluator, fused on-device post-processing + C++ merger; weights that emit
+    full-length varied base strings (`weights.base_calling_weights`; untrained weights cannot call the read correctly:
+    `merged_bases` / `merged_over_reference` say how much the merger stitched, they are not an accuracy).  Host buffers
     in, merged read out; chunking / event detection are outside the metric as in the reference (:32-45)."""
     import numpy as np
     T_r, T_e = 200, 30
@@ -128,10 +132,10 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent
     L = int(nuc.shape[1])
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=slab, max_raw_len=T_r, max_event_len=T_e,
                        max_output_len=max(L, 2), device=device)
-    flat = rv.weights.init_weights(bc.cfg, seed=22, gain=3.0)
-    flat["b_fc"][3:7] += 1.5; flat["b_fc"][bc.cfg.end_token] -= 3.0
-    bc.set_weights_flat(flat)
-    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=not pipelined, pipelined_merge=pipelined, concurrent_slabs=concurrent)
+    # calls of L - 1 varied letters: every chunk is longer than the merger's 25-letter overlap, so the read really is spliced and grows
+    # (the round-2 weights emitted calls of <= 25 letters: 7.6 k alignments ran and the merged read stayed at 145 bases)
+    bc.set_weights_flat(rv.weights.base_calling_weights(bc.cfg))
+    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True, pipelined_merge=pipelined, concurrent_slabs=concurrent)
     e.run_slabs(raw[:slab], ev[:slab], nuc[:slab], chunk_size=slab)          # warm-up
     best = None
     for _ in range(3):
@@ -144,9 +148,11 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent
     return {"workload": f"one synthetic read of {n_bases} bases -> {n_chunks} chunks (joint <=200+<=30, stride 6), beam 5, L {L}, slabs "
                         f"of {slab}, base-emitting weights, fused post-processing + C++ merger"
                         + (" pipelined behind the GPU" if pipelined else "")
-                        + (f", {concurrent} handles decoding consecutive slabs at once" if concurrent > 1 else ""),
+                        + f", {max(concurrent, 2)} slabs in flight (asynchronous calls)",
             "kbases_per_s": round(n_bases / tp / 1000.0, 2), "chunks_per_s": round(n_chunks / tp, 1),
             "bases_num": n_bases, "merged_bases": len(best["merged_seq"]),
+            "merged_over_reference": round(len(best["merged_seq"]) / n_bases, 3),
+            "call_letters_min": int(min(len(s) for s, _ in best["nuc_preds"])),
             "t_predicting": round(best["t_predicting"], 5), "t_postprocessing": round(best["t_postprocessing"], 5),
             "t_merge": round(best["t_merge"], 5), "total_processing": round(tp, 5)}
 
@@ -211,6 +217,10 @@ def main():
     ap.add_argument("--event-len", type=int, default=30)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-output-len", type=int, default=48)
+    ap.add_argument("--recurrence", default="mx", choices=["mx", "fma", "auto"],
+                    help="library option wide_recurrence: mx = matrix-pipe recurrence, 16 chunks per workgroup (library default); "
+                         "fma = packed-FMA kernels; auto = per call by chunks in flight")
+    ap.add_argument("--depth", type=int, default=6, help="slabs in flight through the asynchronous calls (1..8); 0 = the synchronous call")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a fixed read of --read-chunks chunks per step, sharded over the GPUs")
     ap.add_argument("--read-chunks", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -263,113 +273,186 @@ def main():
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
     lo, hi = rv.dist.shard_range(n_global, rank, world)
 
-    def step():
-        if world > 1:   # the shipped multi-GPU path: shard -> decode -> ONE all-gather (RCCL over xGMI)
-            return rv.dist.sharded_beam_search(bc, d_raw, d_ev, W, L, slab=B)
-        out = None
-        for a in range(0, n_global, B):
-            out = bc.beam_search_prediction((d_raw[a:a + B], d_ev[a:a + B]), beam_width=W, max_output_len=L)
-        return out
+    depth = max(0, min(args.depth, 8))
+    if depth:
+        bc.set_async_depth(depth)
+    bc.set_option("wide_recurrence", {"mx": 1, "fma": 0, "auto": -1}[args.recurrence])
+    slabs_of_step = [(d_raw[a:a + B], d_ev[a:a + B]) for a in range(lo, hi, B)] if world == 1 else None
+
+    def run_steps(k):
+        """k steps; returns (last result, per-step completion times).  depth > 0: the steps' slabs stream through the asynchronous
+        calls, `depth` in flight; a step is complete when its last slab is collected.  N > 1: the shipped multi-GPU path, shard ->
+        decode -> ONE all-gather (RCCL over xGMI) per step, the next step's shard submitted before this one is gathered."""
+        out, stamps = None, []
+        if world > 1:
+            if depth:
+                for out in rv.dist.sharded_beam_search_stream(bc, ((d_raw, d_ev) for _ in range(k)), W, L, slab=B):
+                    stamps.append(time.perf_counter())
+            else:
+                for _ in range(k):
+                    out = rv.dist.sharded_beam_search(bc, d_raw, d_ev, W, L, slab=B)
+                    stamps.append(time.perf_counter())
+            return out, stamps
+        if depth:
+            n, per = 0, len(slabs_of_step)
+            for out in bc.beam_search_stream((x for _ in range(k) for x in slabs_of_step), W, L):
+                n += 1
+                if n % per == 0:
+                    stamps.append(time.perf_counter())
+            return out, stamps
+        for _ in range(k):
+            for x in slabs_of_step:
+                out = bc.beam_search_prediction(x, beam_width=W, max_output_len=L)
+            stamps.append(time.perf_counter())
+        return out, stamps
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipEvents on the library's stream, live in the timed region, around the dominant launch (the decode) only:
+    # hipEvents on the library's streams, live in the timed region, around the dominant launch (the decode) only:
     # events around all ~12 launches of a slab cost 2.6 % of it; the other kernels are timed in an untimed pass below
     bc.set_option("profile", 3)
     import gc
     gc.collect(); gc.disable()             # before the warm-up: a collection between warm-up and timing idles the GPU (~50 ms)
-    for _ in range(max(args.warmup, 1)):   # (>=1: graph capture and event pool are built here, not in the timed region)
-        step()
+    run_steps(max(args.warmup, 1))         # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
     bc.reset_profile()
     fence()
     t0 = time.perf_counter()
-    per_step = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        tok, sc = step()
-        per_step.append(time.perf_counter() - ts)
+    (tok, sc), stamps = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    per_step = [b - a for a, b in zip([t0] + stamps[:-1], stamps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof_dec = bc.profile()            # decode launch(es), measured inside the timed region
-    prof = dict(prof_dec)
+    prof_dec = bc.profile()            # decode launch(es), measured inside the timed region (all slabs in flight around them)
     slabs_per_step = -(-(hi - lo) // B)            # this rank's launches of each kernel per step
     x0 = (d_raw[lo:lo + B], d_ev[lo:lo + B])       # this rank's first slab: what the untimed per-kernel passes run on
     Bk = int(x0[0].shape[0])
-    chunk_steps = None
-    if rank == 0:                      # every launch, in a short untimed pass (local decode only: no collective here)
-        n_pass = min(args.steps * slabs_per_step, 10)
+    chunk_steps, prof_iso, sync_ms = None, {}, None
+    # which recurrence form the timed region ran (auto: the matrix form when more than 256 chunks are in flight together)
+    wide_used = {"mx": True, "fma": False, "auto": Bk * max(depth, 1) > 256}[args.recurrence]
+    if rank == 0:
+        # every launch ALONE on the chip, in a short untimed pass of synchronous calls with the timed region's kernel selection
+        # (local decode only: no collective here)
+        bc.set_option("wide_recurrence", 1 if wide_used else 0)
         bc.set_option("profile", 1)
         bc.reset_profile()
-        for _ in range(n_pass):
+        for _ in range(10):
             tk0, _ = bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
-        scale = args.steps * slabs_per_step / n_pass
-        prof = {k: (v[0] * scale, v[1] * scale) for k, v in bc.profile().items()}   # scaled to the timed region's launch count
-        prof.update(prof_dec)
+        prof_iso = {k: v[0] / max(v[1], 1) for k, v in bc.profile().items()}        # ms per launch
         S = int(tk0.shape[1])
         if not args.per_step_decode:
             chunk_steps = bc.get_tensor("chunk_steps").astype(int)
+        bc.set_option("wide_recurrence", -1)
+        bc.set_option("profile", 0)
+        if world == 1:                 # the synchronous call's rate, beside the headline (untimed extra; recurrence form chosen per call)
+            gc.collect(); gc.disable()
+            for _ in range(3):
+                bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(20):
+                bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
+            torch.cuda.synchronize()
+            sync_ms = (time.perf_counter() - ts) / 20 * 1e3
+            gc.enable()
     if os.environ.get("RV_BENCH_VERBOSE"):
         print("per-step ms:", " ".join(f"{x*1e3:.2f}" for x in per_step), file=sys.stderr)
 
     if rank == 0:
         chunks_per_s = n_global * args.steps / dt
-        launches = args.steps * slabs_per_step
         # Per-kernel view of the decode graph: a short extra pass with hipEvents around EVERY kernel
         # (option profile=2: the graph is bypassed, same kernels, same stream).  Not part of `value`.
         dec = {}
-        if not args.no_kernel_pass:
+        if not args.no_kernel_pass and args.per_step_decode:
             bc.set_option("profile", 2)
             bc.reset_profile()
             for _ in range(3):     # local decode only: no collective here (this block runs on rank 0 alone)
                 bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
             dec = {k: v for k, v in bc.profile().items() if k.startswith("dec_") and k != "dec_finalize"}
             bc.set_option("profile", 1)
-        # time per slab of every kernel name (graph replaced by its members when available)
-        per_slab = {k: v[0] / launches for k, v in prof.items()}
+        per_slab = dict(prof_iso)                  # ms per launch of every kernel name, alone on the chip
         if dec:
             per_slab.pop("decode_graph", None)
             for k, (ms, n) in dec.items():
                 per_slab[k] = ms / 3.0
-        name = max(per_slab, key=per_slab.get)                    # dominant kernel
-        # two launches are within a per cent of each other at C3; when that happens report the one whose kernel name is unique in a
-        # rocprofv3 summary (the fused recurrence kernel runs under one name for the raw and the event encoder)
-        if "dec_persist" in per_slab and per_slab["dec_persist"] >= 0.97 * per_slab[name]:
-            name = "dec_persist"
-        # the decode launch is timed inside the timed region (profile 3); other kernels come from the untimed passes
-        ms, n = prof_dec[name] if name in prof_dec else (dec[name] if name in dec else prof[name])
-        avg_ms = ms / max(n, 1)
-        by = algorithmic_bytes(name, Bk, T_r, T_e, W, S)
-        if by:
-            achieved = by / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": n,
-                    "bytes_per_launch": by, "traffic": None}
+        # workgroups per launch -> the share of the chip a launch can use, and from it the kernel's CU-time per slab: with several
+        # slabs in flight that, not the launch duration, is what a kernel costs the whole job
+        Tm = T_r + T_e
+        wgs = {"dec_persist": Bk, "dec_finalize": 0, "input_mask": 0,
+               "gemm_memory": min(256, -(-(Bk * Tm) // 128)), "gemm_inproj_raw": min(256, -(-(Bk * T_r) // 128)),
+               "gemm_inproj_event": min(256, -(-(Bk * T_e) // 128)), "inproj_event_l0": 256}
+        def rows_per_block(b):          # the library's pick_rows_per_block
+            bt, r = (2 * b + 255) // 256, 1
+            while r < bt and r < 8:
+                r <<= 1
+            return r
+        rec_wgs = 2 * -(-Bk // 16) if wide_used else 2 * -(-Bk // rows_per_block(Bk))
+        for k in per_slab:
+            if k.startswith("lstm_rec"):
+                wgs[k] = rec_wgs
+        cu_ms = {k: v * min(1.0, wgs.get(k, 256) / 256.0) for k, v in per_slab.items()}
+        order = sorted(cu_ms, key=cu_ms.get, reverse=True)
+
+        pmc = {}
+        for fn in ("hbm_traffic.json", "mfma_util.json"):
+            path = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(path):
+                with open(path) as f:
+                    pmc[fn] = json.load(f)
+
+        def roof_of(name, avg_ms, launches, where):
+            by = algorithmic_bytes(name, Bk, T_r, T_e, W, S)
+            if by:
+                achieved = by / (avg_ms * 1e-3) / 1e9
+                r = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                     "bytes_per_launch": by, "traffic": None}
+            else:
+                fl_ref = algorithmic_flops(name, Bk, T_r, T_e, W, S)
+                fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, chunk_steps) if fl_ref else None
+                achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
+                r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
+                     "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
+                     "avg_launch_ms": round(avg_ms, 5), "launches": launches, "flops_per_launch": fl,
+                     "flops_reference": fl_ref, "flops_executed": fl, "traffic": None}
+            r["measured"] = where
+            # rocprof PMC figures of the same kernel, collected on synchronous calls of this workload (tools/collect_traffic.sh,
+            # tools/pmc_mfma.sh -> profiles/): HBM bytes per launch -> GB/s against the 8 TB/s peak; matrix-pipe busy fraction
+            key = ("wide:" if wide_used else "fma:") + name
+            t = pmc.get("hbm_traffic.json", {}).get(key)
+            if t and Bk == 256:
+                r["traffic"] = t["hbm_bytes_per_launch"]
+                iso = per_slab.get(name, avg_ms)
+                r["hbm_gbps"] = round(t["hbm_bytes_per_launch"] / (iso * 1e-3) / 1e9, 1)
+                r["hbm_frac_of_peak"] = round(r["hbm_gbps"] / PEAK_HBM_GBS, 4)
+                r["hbm_note"] = "PMC bytes per launch / the launch's duration alone on the chip"
+            m = pmc.get("mfma_util.json", {}).get(key)
+            if m and Bk == 256:
+                r["mfma_util"] = m["mfma_util"]
+                r["mfma_util_note"] = m.get("note", "")
+            return r
+
+        name = order[0]
+        if name in prof_dec:            # the decode launch is timed inside the timed region (profile 3), other slabs in flight around it
+            ms, n = prof_dec[name]
+            roof = roof_of(name, ms / max(n, 1), n, f"hipEvents inside the timed region, {max(depth, 1)} slab(s) in flight")
         else:
-            fl_ref = algorithmic_flops(name, Bk, T_r, T_e, W, S)
-            fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, chunk_steps) if fl_ref else None
-            achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
-                    "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
-                    "avg_launch_ms": round(avg_ms, 5), "launches": n, "flops_per_launch": fl,
-                    "flops_reference": fl_ref, "flops_executed": fl, "traffic": None}
-        roof["share_of_slab_time"] = round(per_slab[name] / sum(per_slab.values()), 3)
+            roof = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass, the launch alone on the chip")
+        roof["share_of_cu_time"] = round(cu_ms[name] / sum(cu_ms.values()), 3)
         if roof["bound"] == "mfma":
             roof["peak_note"] = PEAK_NOTE
-        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                for k, v in json.load(f).items():
-                    if k.split("@")[0] == name and Bk == 256:          # collected on this workload only
-                        roof["traffic"] = v["hbm_bytes_per_launch"]
+        roof_iso = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass of synchronous calls, the launch alone on the chip")
+        top2 = [roof_of(k, per_slab[k], 10, "hipEvents, untimed pass, the launch alone on the chip") for k in order[1:3]
+                if algorithmic_flops(k, Bk, T_r, T_e, W, S)]
+        for r, k in zip(top2, [k for k in order[1:3] if algorithmic_flops(k, Bk, T_r, T_e, W, S)]):
+            r["share_of_cu_time"] = round(cu_ms[k] / sum(cu_ms.values()), 3)
         # whole-path view (SURVEY.md 8d): algorithmic FLOPs of the path / step time vs the fp32 peak.  `flops_reference`
         # credits the decode with B*W*S row-steps (the reference's slab-wide loop); `flops_executed` with the chunk-steps
         # the persistent decode really ran on this rank's first slab (a chunk leaves the loop once its beams are finished).
@@ -379,7 +462,6 @@ def main():
         path_exec = enc_fl + W * exec_steps * DEC_FLOPS(T_r + T_e)
         tf_ref = n_global * path_ref / (dt / args.steps) / 1e12
         tf_exec = n_global * path_exec / (dt / args.steps) / 1e12
-        total_ms = sum(v[0] for v in prof.values())
         mode = "strong" if args.strong else "weak"
         out = {
             "metric": "kbases/s, raw+event joint mode, beam=5 (hot path: beam_search_prediction)",
@@ -394,25 +476,36 @@ def main():
                                    + f", max_output_len={L}, enc_depth=2, dec_depth=1, units=128, luong",
                        "decode_steps": S, "decode_steps_executed_mean": round(exec_steps, 2),
                        "weights": "random-init (Keras defaults, seed 22)",
-                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step (dist.sharded_beam_search)" if world > 1 else "")},
+                       "pipelining": (f"the {args.steps} timed steps stream through the asynchronous calls (rv_beam_search_submit_dev / collect_dev), "
+                                      f"{depth} slabs in flight, every step collected inside the timed region; results byte-identical to the synchronous call"
+                                      if depth else "synchronous calls, one slab at a time"),
+                       "recurrence": ("matrix pipe, 16 chunks per workgroup (k_lstm_rec_mx + split-f16 projection GEMM)" if wide_used
+                                      else "packed fp32 FMAs (k_lstm_rec_tw / k_lstm_rec_proj)"),
+                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if world > 1 else "")},
             "roofline": roof,
+            "roofline_isolated": roof_iso,
+            "roofline_top2": top2,
             "roofline_path": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
                               "frac": round(tf_exec / (PEAK_F32_TFLOPS * world), 4),
                               "flops_per_chunk_reference": path_ref, "flops_per_chunk_executed": round(path_exec),
                               "achieved_reference": round(tf_ref, 2), "frac_reference": round(tf_ref / (PEAK_F32_TFLOPS * world), 4),
                               "peak_note": PEAK_NOTE},
-            "kernel_ms_per_slab": {k: round(v, 4) for k, v in sorted(per_slab.items())},
+            "kernel_ms_per_launch_alone": {k: round(v, 4) for k, v in sorted(per_slab.items())},
+            "kernel_cu_ms_per_slab": {k: round(v, 4) for k, v in sorted(cu_ms.items())},
             "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
-            "device_ms_per_step": round(total_ms / args.steps, 4),
             "step_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
         }
+        if sync_ms is not None:
+            out["synchronous"] = {"ms_per_step": round(sync_ms, 4), "chunks_per_s": round(Bk / sync_ms * 1e3, 1),
+                                  "note": "rv_beam_search_dev, one slab at a time, wide_recurrence = -1 (per-call choice: the packed-FMA kernels "
+                                          "for one isolated slab of <= 256 chunks); untimed extra: 20 calls after the timed region"}
     bc.close()
     if rank == 0:
         if world == 1 and not args.no_extras:      # sub-lines outside the timed region (own handles)
             try:
                 out["read_level"] = read_level(rv, local)
                 out["read_level_pipelined"] = read_level(rv, local, pipelined=True)
-                out["read_level_concurrent"] = read_level(rv, local, pipelined=True, concurrent=2)
+                out["read_level_concurrent"] = read_level(rv, local, pipelined=True, concurrent=4)
                 out["bahdanau"] = bahdanau_timing(rv, local, B, T_r, T_e, W, L)
             except Exception as e:
                 out["extras_error"] = repr(e)

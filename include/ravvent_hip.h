@@ -96,6 +96,27 @@ int rv_beam_search_calls(rv_handle h, const float* raw, const float* event, int3
                          int32_t T_e, int32_t W, int32_t L, const uint8_t* lut, uint8_t* bases,
                          int32_t* lengths, float* probs, int32_t* S_out);
 
+/* Asynchronous form of rv_beam_search* (no counterpart in the reference, whose evaluator decodes one slab at a time:
+ * ravvent_performance_evaluator.py:51-55).  The handle owns "async_depth" slab contexts (own stream and buffers, one set of
+ * weights); rv_beam_search_submit* queues a slab's whole path on an idle context and returns a ticket without waiting for the
+ * GPU, rv_beam_search_collect* waits for that slab and hands out its results, which are byte-identical to the synchronous
+ * call's.  Up to async_depth slabs are in flight: slab k+1's encoders run beside the tail of slab k's decode (chunks leave the
+ * decode as their beams finish), and with several slabs in flight the encoder recurrences switch to 16 chunks per workgroup on
+ * the matrix pipe (option "wide_recurrence").  Tickets may be collected in any order; submit fails with RV_ESTATE when every
+ * context holds an uncollected call.  Same single-thread rule as the rest of the handle.
+ *   submit       : host inputs, copied to pinned staging before the call returns (the caller may reuse its buffers at once)
+ *   submit_dev   : device inputs and outputs; they must stay valid and untouched until the ticket is collected
+ *   submit_calls : the fused post-processing of rv_beam_search_calls */
+int rv_beam_search_submit(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                          int32_t W, int32_t L, int32_t* ticket);
+int rv_beam_search_collect(rv_handle h, int32_t ticket, int32_t* tokens, float* scores, int32_t* S_out);
+int rv_beam_search_submit_dev(rv_handle h, const float* d_raw, const float* d_event, int32_t B, int32_t T_r, int32_t T_e,
+                              int32_t W, int32_t L, int32_t* d_tokens, float* d_scores, int32_t* ticket);
+int rv_beam_search_collect_dev(rv_handle h, int32_t ticket, int32_t* S_out);
+int rv_beam_search_submit_calls(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e,
+                                int32_t W, int32_t L, const uint8_t* lut, int32_t* ticket);
+int rv_beam_search_collect_calls(rv_handle h, int32_t ticket, uint8_t* bases, int32_t* lengths, float* probs, int32_t* S_out);
+
 /* Basecaller.greedy_search_prediction (basecaller.py:317-330): tokens = sample_id [B, L-1],
  * logits = rnn_output [B, L-1, vocab]; columns >= S are pad_token / 0. */
 int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r,
@@ -123,6 +144,16 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "tail_wave"  (0/1, default 1: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
  *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
  *                       agree to fp32 rounding),
+ *          "wide_recurrence" (1/0/-1, default 1: the encoder recurrences as ONE split-f16 MFMA product per step for 16 chunks of a
+ *                       direction per workgroup (raw layer 0 with its input projection in the lane, the other layers on inputs
+ *                       pre-projected by an elementwise kernel / a split-f16 GEMM); 0 = packed fp32 FMAs on 1-8 chunks per
+ *                       workgroup with the projection fused in ("fused_projection", "split_projection", "tail_wave" configure that
+ *                       form).  The matrix form costs per workgroup, the FMA form per chunk: the matrix form wins as soon as more
+ *                       than 256 chunks are in flight (one large slab, or several through the asynchronous calls), the FMA form has
+ *                       the lower latency for ONE isolated slab of <= 256 chunks (C3 shape: 1.40 vs 1.86 ms).  -1 = choose per call
+ *                       by that rule -- fastest, but the two forms agree to f32 rounding only, so results then depend on the slab
+ *                       size; with 1 or 0 a chunk's result never depends on the slab or shard it travels in),
+ *          "async_depth" (1..8, default 2: contexts the rv_beam_search_submit* calls rotate through),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

@@ -6,6 +6,14 @@ decoder with Luong / Bahdanau attention and beam search -- as hand-written HIP k
 the C-ABI of include/ravvent_hip.h, with the reference's `Basecaller` class API in front.
 There is no CPU fallback: without the HIP library the path raises.
 """
+import os as _os
+
+# The asynchronous calls keep several slabs in flight, one HIP stream per slab context.  The ROCm runtime multiplexes a process's
+# streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with 4+ contexts two of them share a queue and serialise
+# (measured at the C3 shape: depth 4 -> 203 k chunks/s on 4 queues, 262 k on 8).  The variable is read when the HIP runtime
+# starts, i.e. at the process's first HIP call -- importing this package first is enough; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .config import RvConfig  # noqa: F401
 from . import data_loader, utils, weights, synthetic, dist, evaluator, event_detection, checkpoint  # noqa: F401
 from .basecaller import Basecaller  # noqa: F401

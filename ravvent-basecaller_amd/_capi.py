@@ -26,6 +26,12 @@ SYMBOLS = [
     ("rv_beam_search", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_beam_search_dev", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_beam_search_calls", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, _I]),
+    ("rv_beam_search_submit", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, _I]),
+    ("rv_beam_search_collect", c_int32, [c_void_p, c_int32, c_void_p, c_void_p, _I]),
+    ("rv_beam_search_submit_dev", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
+    ("rv_beam_search_collect_dev", c_int32, [c_void_p, c_int32, _I]),
+    ("rv_beam_search_submit_calls", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, _I]),
+    ("rv_beam_search_collect_calls", c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, _I]),
     ("rv_greedy_search", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_greedy_search_dev", c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, _I]),
     ("rv_set_option", c_int32, [c_void_p, c_char_p, c_int32]),

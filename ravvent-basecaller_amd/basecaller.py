@@ -207,6 +207,100 @@ class Basecaller:
         self.last_steps = S.value
         return tokens[:, :S.value], scores[:, :S.value]
 
+    # ------------------------------------------------------------------ the hot path, several slabs in flight
+    def set_async_depth(self, depth: int):
+        """Slab contexts the submit_* calls rotate through (1..8; default 2).  With several slabs in flight the GPU never idles
+        at a slab boundary, and the encoder recurrences run 16 chunks per workgroup on the matrix pipe (option wide_recurrence)."""
+        self.set_option("async_depth", int(depth))
+        self.async_depth = int(depth)
+
+    def submit_beam_search(self, input_data, beam_width, max_output_len):
+        """Queue `beam_search_prediction(input_data, ...)` without waiting for the GPU (rv_beam_search_submit / _submit_dev);
+        returns a ticket for `collect`.  Results are byte-identical to the synchronous call.  Device inputs must stay untouched
+        until the ticket is collected (the ticket keeps them alive)."""
+        keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
+        L, W = _as_int(max_output_len), int(beam_width)
+        steps = max(L - 1, 0)
+        t = ctypes.c_int32(-1)
+        call = {"kind": "dev" if on_dev else "host", "keep": keep, "B": B, "steps": steps}
+        if on_dev:
+            torch.cuda.current_stream(self.device).synchronize()
+            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
+            scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
+            call["out"] = (tokens, scores)
+            rc = self._lib.rv_beam_search_submit_dev(self._h, pr, pe, B, Tr, Te, W, L, ctypes.c_void_p(tokens.data_ptr()),
+                                                     ctypes.c_void_p(scores.data_ptr()), ctypes.byref(t))
+        else:
+            rc = self._lib.rv_beam_search_submit(self._h, pr, pe, B, Tr, Te, W, L, ctypes.byref(t))
+        self._check(rc, "rv_beam_search_submit")
+        call["ticket"] = t.value
+        return call
+
+    def collect(self, call):
+        """Wait for a `submit_beam_search` ticket -> (predicted_ids[:,:,0] [B,S] int32, scores[:,:,0] [B,S] f32)."""
+        S = ctypes.c_int32(0)
+        if call["kind"] == "dev":
+            self._check(self._lib.rv_beam_search_collect_dev(self._h, call["ticket"], ctypes.byref(S)), "rv_beam_search_collect_dev")
+            tokens, scores = call["out"]
+        elif call["kind"] == "host":
+            tk = np.empty((call["B"], call["steps"]), np.int32)
+            sc = np.empty((call["B"], call["steps"]), np.float32)
+            self._check(self._lib.rv_beam_search_collect(self._h, call["ticket"], tk.ctypes.data_as(ctypes.c_void_p),
+                                                         sc.ctypes.data_as(ctypes.c_void_p), ctypes.byref(S)), "rv_beam_search_collect")
+            tokens, scores = torch.from_numpy(tk), torch.from_numpy(sc)
+        else:
+            raise ValueError("collect_calls() takes the tickets of submit_calls()")
+        call["keep"] = None
+        self.last_steps = S.value
+        return tokens[:, :S.value], scores[:, :S.value]
+
+    def _call_lut(self):
+        lut = np.zeros(8, np.uint8)
+        for idx, word in self.tokenizer.index_word.items():
+            if 0 <= idx < 8 and word not in ("", "^", "$", " "):
+                lut[idx] = ord(word.upper())
+        return lut
+
+    def submit_calls(self, input_data, beam_width, max_output_len):
+        """Asynchronous `beam_search_call_arrays` (rv_beam_search_submit_calls): host inputs, fused on-device post-processing."""
+        keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
+        if on_dev:
+            host = tuple(None if k is None else k.cpu().numpy() for k in keep)
+            return self.submit_calls(host if self.input_data_type == "joint" else (host[0] if host[0] is not None else host[1]),
+                                     beam_width, max_output_len)
+        L = _as_int(max_output_len)
+        t = ctypes.c_int32(-1)
+        lut = self._call_lut()
+        self._check(self._lib.rv_beam_search_submit_calls(self._h, pr, pe, B, Tr, Te, int(beam_width), L,
+                                                          lut.ctypes.data_as(ctypes.c_void_p), ctypes.byref(t)), "rv_beam_search_submit_calls")
+        return {"kind": "calls", "ticket": t.value, "B": B, "steps": max(L - 1, 0)}
+
+    def collect_calls(self, call):
+        """-> (bases u8 [B, L-1], probs f32 [B, L-1], lengths i32 [B]) of a `submit_calls` ticket."""
+        B, steps = call["B"], call["steps"]
+        bases = np.zeros((B, steps), np.uint8); lens = np.zeros(B, np.int32); probs = np.zeros((B, steps), np.float32)
+        S = ctypes.c_int32(0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._lib.rv_beam_search_collect_calls(self._h, call["ticket"], p(bases), p(lens), p(probs), ctypes.byref(S)),
+                    "rv_beam_search_collect_calls")
+        self.last_steps = S.value
+        return bases, probs, lens
+
+    def beam_search_stream(self, slabs, beam_width, max_output_len, calls: bool = False):
+        """Generator: decode an iterable of slabs with `async_depth` of them in flight, yielding each slab's result in order
+        ((tokens, scores), or (bases, probs, lengths) with calls=True) -- the overlapped form of a loop over
+        `beam_search_prediction` / `beam_search_call_arrays`, with identical results."""
+        depth = getattr(self, "async_depth", 2)
+        sub = self.submit_calls if calls else self.submit_beam_search
+        col = self.collect_calls if calls else self.collect
+        queue = []
+        for x in slabs:
+            if len(queue) >= depth:
+                yield col(queue.pop(0))
+            queue.append(sub(x, beam_width, max_output_len))
+        while queue:
+            yield col(queue.pop(0))
+
     def greedy_search_prediction(self, input_data, max_output_len):
         """basecaller.py:317-330 -> (sample_id [B,S] int32, rnn_output logits [B,S,V] f32)."""
         keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
@@ -259,10 +353,7 @@ class Basecaller:
                                           beam_width, max_output_len, arrays)
         L = _as_int(max_output_len)
         steps = max(L - 1, 0)
-        lut = np.zeros(8, np.uint8)
-        for idx, word in self.tokenizer.index_word.items():
-            if 0 <= idx < 8 and word not in ("", "^", "$", " "):
-                lut[idx] = ord(word.upper())
+        lut = self._call_lut()
         bases = np.zeros((B, steps), np.uint8); lens = np.zeros(B, np.int32); probs = np.zeros((B, steps), np.float32)
         S = ctypes.c_int32(0)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)

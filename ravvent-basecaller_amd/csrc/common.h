@@ -22,6 +22,8 @@ struct RecArgs {
   const float* Wp[2];    // fused-projection kernel only: input kernel [256,512] as MFMA B fragments [32 tiles][16 k-groups][64 lanes][4]
   const uint16_t* Wsb[2];  // the same kernel as three bf16 parts for the split-bf16 projection, [32 tiles][3 parts][8 k-steps][64 lanes][8]; null = f32 MFMA
   const uint16_t* Wh[2];   // ... as two f16 parts of the column-scaled kernel, [32 tiles][2 parts][8 k-steps][64 lanes][8], then 512 floats 2^-14 / s_n; takes precedence over Wsb
+  const uint16_t* Ua[2];   // matrix-pipe recurrence (lstm_mx.hip): U^T as MFMA A fragments, [8 waves][4 gates][4 k-steps][2 parts][64 lanes][8 f16]
+                           // of the row-scaled kernel, then 512 floats 2^-14 / s_r (RV_UA_SLOT uint16 per direction)
   const float* h0[2];    // initial states [B,128] or nullptr (zeros)
   const float* c0[2];
   float* hT[2];          // final states [B,128]
@@ -38,6 +40,15 @@ void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s)
 // layers >= 1 with x . W + b computed inside the kernel (MFMA waves beside the recurrence waves): a.x = [B,T,256] activations,
 // a.Wp / a.bias per direction
 void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
+// Matrix-pipe recurrence, RV_MX_ROWS chunks of one direction per workgroup (lstm_mx.hip).  F == 1: raw layer 0 (a.x = chunk inputs
+// [B,T,1], a.W / a.bias per direction); F == 0: a.x = pre-projected inputs xw [B,T,2,512] (bias folded).  Needs a.Ua.
+#define RV_MX_ROWS 16
+#define RV_UA_SLOT ((size_t)2 * RV_U * RV_G + 2 * RV_G)
+void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s);
+bool lstm_rec_mx_window_fits(int T);
+hipError_t configure_mx_kernels();
+// xw [rows,2,512] = x [rows,F] . W_dir [F,512] + b_dir for a layer-0 encoder with F = 5 (or 1) input features, both directions
+void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw, hipStream_t s);
 hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the recurrence kernels; first error or hipSuccess
 // layer 0 stages its chunks' whole input windows in LDS: does a window of T steps x F features fit with that many rows per workgroup?
 bool lstm_rec_window_fits(int F, int rows_per_block, int T);
@@ -62,6 +73,12 @@ void launch_gemm_f32(const GemmArgs& a, bool small_tile, hipStream_t s);
 // kernel, then 256 floats 2^-14 / s_n (RV_WMP16_SLOT uint16).  Precondition: |A| <= 1 (rows of an LSTM layer's output).
 #define RV_WMP16_SLOT ((size_t)2 * RV_E * RV_E + 2 * RV_E)
 void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s);
+// The same kernel over `ncb` column blocks of 256: C[M, ldc] (columns 256 cb ..) = A[M,256] . W_cb[256,256] (+ bias[256 cb ..]);
+// img = [ncb][8 k-steps][16 tiles][2 parts][64 lanes][8 f16], then 256 ncb floats 2^-14 / s_n.  A workgroup takes the ncb blocks of a
+// row tile one after the other, so A comes from HBM once.  The input projection of encoder layers >= 1 for the matrix-pipe
+// recurrence: ncb = 4 (two directions x 512 gate columns), ldc = 1024, bias = [b_fwd | b_bwd].
+#define RV_WX16_SLOT ((size_t)2 * RV_E * 2 * RV_G + 2 * 2 * RV_G)
+void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int ncb, const float* bias, float* C, int ldc, hipStream_t s);
 
 // ---------------------------------------------------------------- small encoder-side kernels
 void launch_input_mask(const float* raw, const float* ev, int B, int T_r, int T_e, float pad,

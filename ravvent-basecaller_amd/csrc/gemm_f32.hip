@@ -172,18 +172,21 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // k-steps ahead.  128-row tiles, persistent: workgroup w takes tiles w, w + gridDim.x, ...  The barriers are raw s_barrier +
 // lgkmcnt(0) (LDS hand-off only): __syncthreads() would also drain the A loads in flight.  The (tile, k-step) pairs of a workgroup form one
 // flat stream: the A floats of stream position it + 2 are requested while position it is multiplied, across tile boundaries too.
+template <int NCB>
 __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict__ A, int M, const uint16_t* __restrict__ img,
-                                                         float* __restrict__ C, int ntiles, int dbg_arg) {
-#ifdef RV_GEMM_DIAG    // timing probes (tools/gemm_probe.sh, `make gemm_diag`): 1 = no C stores, 2 = no A loads, 4 = no MFMAs; results invalid
+                                                         float* __restrict__ C, int ntiles, int dbg_arg, int ldc,
+                                                         const float* __restrict__ bias) {
+  constexpr int ncb = NCB;
+  // dbg: timing probes (1 = no C stores, 2 = no A loads, 4 = no MFMAs; results invalid).  The launcher passes 0 unless the library
+  // was built with -DRV_GEMM_DIAG (`make gemm_diag`, tools/gemm_probe.sh).  It stays a RUN-TIME value on purpose: the never-taken
+  // branches keep the scheduler from hoisting a k-step's 32 fragment reads above its MFMAs (as a compile-time 0 the kernel goes
+  // from 213 to 256 VGPRs and spills).
   const int dbg = dbg_arg;
-#else
-  constexpr int dbg = 0;
-  (void)dbg_arg;
-#endif
   __shared__ __align__(16) char Bs[3][32768];
-  __shared__ __align__(16) float css[RV_E];
+  __shared__ __align__(16) float css[4 * RV_E];            // column factors of up to 4 column blocks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+  // a workgroup's stream: its row tiles (blockIdx.x, + gridDim.x, ...), and for each of them the ncb column blocks in turn
+  const int nloc = ncb * ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);     // (tile, column block) pairs (>= 1)
 #define RV_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
   if (wave >= 4) {                                         // ---------------- loader role
     // slab -> LDS by LDS-DMA (16 x 1 KB per wave, no staging registers, no ds_write): thread p moves bytes [16 p + 2048 i, +16);
@@ -191,10 +194,11 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
     // of iteration it (its buffer was last read in it - 1), slab it + 1 must have landed at its end: vmcnt(16) = all but
     // the youngest batch.
     const int p = tid - 256;                               // 0..127
-    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)8 * 32768);
-    css[p] = cs[p]; css[p + 128] = cs[p + 128];
+    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)ncb * 8 * 32768);
+    for (int i = p; i < ncb * RV_E; i += 128) css[i] = cs[i];
+    const int nslab = 8 * ncb;
     auto dma = [&](int slab) {
-      const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab & 7) * 32768 + p * 16;
+      const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab % nslab) * 32768 + p * 16;
       char* dst = Bs[slab % 3] + (wave - 4) * 1024;
 #pragma unroll
       for (int i = 0; i < 16; ++i)
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
   RV_A_LOAD((int)blockIdx.x, 1, a1);
   RV_LDS_BARRIER();
   for (int n = 0; n < nloc; ++n) {
-    const int tile = blockIdx.x + n * gridDim.x;
-    const int tnext = n + 1 < nloc ? tile + (int)gridDim.x : tile;      // (the last tile re-reads two of its own k-steps: L2 hits, dropped)
+    const int tile = blockIdx.x + (n / ncb) * gridDim.x, cb = n % ncb;
+    const int tnext = n + 1 < nloc ? (int)blockIdx.x + ((n + 1) / ncb) * (int)gridDim.x : tile;      // (the last pair re-reads two of its own k-steps: L2 hits, dropped)
     f4v acc[2][16];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -269,9 +273,11 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
       if (row < M && !(dbg & 1)) {                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
-          const float4 f = *reinterpret_cast<const float4*>(&css[16 * nt + 4 * q]);
-          *reinterpret_cast<float4*>(&C[(size_t)row * RV_E + 16 * nt + 4 * q]) =
-              make_float4(acc[m][nt][0] * f.x, acc[m][nt][1] * f.y, acc[m][nt][2] * f.z, acc[m][nt][3] * f.w);
+          const int col = cb * RV_E + 16 * nt + 4 * q;
+          const float4 f = *reinterpret_cast<const float4*>(&css[col]);
+          float4 o = make_float4(acc[m][nt][0] * f.x, acc[m][nt][1] * f.y, acc[m][nt][2] * f.z, acc[m][nt][3] * f.w);
+          if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + col); o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+          *reinterpret_cast<float4*>(&C[(size_t)row * ldc + col]) = o;
         }
       }
     }
@@ -280,12 +286,18 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
 #undef RV_A_LOAD
 }
 
-void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
+void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int ncb, const float* bias, float* C, int ldc, hipStream_t s) {
   const int nt128 = (M + 127) / 128;
   int dbg = 0;
 #ifdef RV_GEMM_DIAG
   static const int dbg_env = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
   dbg = dbg_env;
 #endif
-  hipLaunchKernelGGL(k_gemm_mem_split3, dim3(nt128 < 256 ? nt128 : 256), dim3(384), 0, s, A, M, img, C, nt128, dbg);
+  const dim3 grid(nt128 < 256 ? nt128 : 256), block(384);
+  if (ncb == 1) hipLaunchKernelGGL(k_gemm_mem_split3<1>, grid, block, 0, s, A, M, img, C, nt128, dbg, ldc, bias);
+  else if (ncb == 4) hipLaunchKernelGGL(k_gemm_mem_split3<4>, grid, block, 0, s, A, M, img, C, nt128, dbg, ldc, bias);
+  else abort();   // (internal: 1 = attention memory, 4 = both directions of an encoder layer)
+}
+void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C, hipStream_t s) {
+  launch_gemm_split_blocks(A, M, img, 1, nullptr, C, RV_E, s);
 }

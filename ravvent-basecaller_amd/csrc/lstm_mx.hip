@@ -1,0 +1,206 @@
+// K1m -- the BiLSTM recurrence on the 16-bit matrix pipe, SIXTEEN chunks per workgroup (replaces the tf.while_loop of LSTMCell
+// steps that Encoder.call drives: /root/reference/basecaller.py:19-32,48-59; cell math SURVEY.md A.1/A.2).
+//
+// The packed-FMA kernels of lstm_rec.hip cost the same per chunk-row however many rows a workgroup holds (2,390 cycles per
+// step for 2 rows, 8,400 for 8): they are bound by fp32 FMA issue.  Here the recurrent product of a step is ONE matrix
+// product per workgroup, z^T [512 gate columns x 16 chunks] = U^T [512 x 128] . h^T [128 x 16], on v_mfma_f32_16x16x32_f16 with
+// split operands (two f16 parts per value, three exact part products, f32 accumulation: DESIGN.md section 4) -- its cost does
+// not depend on how many of the 16 columns are in use, so a workgroup takes 16 chunks of ONE direction:
+//   * U^T stays resident as A fragments: wave w owns units 16 w .. 16 w + 15 of all four gates = 4 row tiles x 4 k-steps x
+//     2 parts x 4 VGPRs = 128 VGPRs (the whole kernel, 256 KB, in the register file of the CU -- as the FMA kernels keep it);
+//   * h^T goes through LDS as B fragments: [part][k-block of 8 units][chunk][8 f16], double-buffered, 1 KB per wave read;
+//   * the C/D layout of the 16x16 tile gives lane (chunk n = lane % 16, q = lane / 16) the four gate sums of units
+//     16 w + 4 q + 0..3 of chunk n: the cell update is local to the lane (no reduction, no gather, no tail waves), c stays in 4
+//     registers, and the new h leaves as one float4 to the layer output and as 4 + 4 f16 to the LDS image;
+//   * one raw s_barrier per step (LDS hand-off only: the next step's pre-projected inputs stay in flight across it).
+// Scales: h' = 2^14 h (|h| <= 1), U' = s_r U with s_r the power of two that brings the largest element of gate column r into
+// [2^13, 2^14); z = acc * (2^-14 / s_r) + (x . W + b).  Layer 0 with one input feature (raw samples) adds x_t W + b in the lane from
+// an LDS-staged window; every other layer reads its pre-projected inputs xw [B,T,2,512] (event layer 0: k_inproj_small; layers
+// >= 1: the split-f16 GEMM of gemm_f32.hip), one float4 per gate per lane, requested a step ahead.
+// The reverse direction walks t = T-1..0 and, as in the reference (no mask is passed, basecaller.py:400,403), starts on the padding.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#define RV_MX_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <int F>
+__global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
+  static_assert(F == 0 || F == 1, "pre-projected inputs, or one raw feature");
+  extern __shared__ __align__(16) char mxsm[];
+  char* hb = mxsm;                                               // [2 buffers][2 parts][16 k-blocks][16 chunks][8 f16] = 16 KB
+  float* dss = reinterpret_cast<float*>(mxsm + 16384);           // [512] 2^-14 / s_r
+  float* wxs = dss + RV_G;                                       // F == 1: [512] input kernel row, [512] bias
+  float* xs = wxs + 2 * RV_G;                                    // F == 1: [16][T] input windows
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int dir = blockIdx.y, b0 = blockIdx.x * RV_MX_ROWS, T = a.T;
+  const int bc = min(b0 + n, a.B - 1);                           // rows beyond the slab compute on a copy of its last chunk, never stored
+  const bool live = b0 + n < a.B;
+  const int u0 = 16 * w + 4 * q;                                 // this lane's 4 units
+
+  // ---- U^T -> registers (A fragments), once
+  float4 ua[4][4][2];
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.Ua[dir]) + (size_t)w * (4 * 4 * 2 * 64) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ua[g][ks][p] = src[((g * 4 + ks) * 2 + p) * 64];
+  }
+  {
+    const float* dsg = reinterpret_cast<const float*>(a.Ua[dir] + (size_t)2 * RV_U * RV_G);
+    dss[tid] = dsg[tid];
+    if (F == 1) {
+      wxs[tid] = a.W[dir][tid]; wxs[RV_G + tid] = a.bias[dir][tid];
+      for (int r = 0; r < RV_MX_ROWS; ++r) {
+        const int b = min(b0 + r, a.B - 1);
+        for (int i = tid; i < T; i += 512) xs[r * T + i] = a.x[(size_t)b * T + i];
+      }
+    }
+  }
+  // ---- initial state: c in registers, h as the first B image
+  float c[4];
+  {
+    float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), c0 = h0;
+    if (a.h0[dir]) { h0 = *reinterpret_cast<const float4*>(a.h0[dir] + (size_t)bc * RV_U + u0); c0 = *reinterpret_cast<const float4*>(a.c0[dir] + (size_t)bc * RV_U + u0); }
+    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+    const float hv[4] = {h0.x, h0.y, h0.z, h0.w};
+    h4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float sv = hv[i] * 16384.f; hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]); }
+    char* dst = hb + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
+    *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
+  }
+  // pre-projected inputs of the first step
+  float4 xc[4], xn[4];
+  const float* xrow = F == 0 ? a.x + ((size_t)bc * T * 2 + dir) * RV_G + u0 : nullptr;    // + t * 1024 + g * 128
+  if (F == 0) {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xc[g] = *reinterpret_cast<const float4*>(xrow + (size_t)t0 * (2 * RV_G) + g * RV_U);
+  }
+  __syncthreads();
+
+  float hl[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    if (F == 0) {                                                // next step's inputs: in flight across the barrier
+      const int tn = dir ? max(t - 1, 0) : min(t + 1, T - 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xn[g] = *reinterpret_cast<const float4*>(xrow + (size_t)tn * (2 * RV_G) + g * RV_U);
+    }
+    f4v acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+    const char* hp = hb + cur * 8192 + (q * 16 + n) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const h8 bh = *reinterpret_cast<const h8*>(hp + ks * 1024), bl = *reinterpret_cast<const h8*>(hp + 4096 + ks * 1024);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const h8 ah = __builtin_bit_cast(h8, ua[g][ks][0]), al = __builtin_bit_cast(h8, ua[g][ks][1]);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
+      }
+    }
+    // ---- gate pre-activations of this lane's 4 units, cell update (i, f, c~, o)
+    float z[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 ds = *reinterpret_cast<const float4*>(&dss[g * RV_U + u0]);
+      float4 xin;
+      if (F == 0) xin = xc[g];
+      else {
+        const float xv = xs[n * T + t];
+        const float4 wv = *reinterpret_cast<const float4*>(&wxs[g * RV_U + u0]), bv = *reinterpret_cast<const float4*>(&wxs[RV_G + g * RV_U + u0]);
+        xin = make_float4(fmaf(xv, wv.x, bv.x), fmaf(xv, wv.y, bv.y), fmaf(xv, wv.z, bv.z), fmaf(xv, wv.w, bv.w));
+      }
+      z[g][0] = fmaf(acc[g][0], ds.x, xin.x); z[g][1] = fmaf(acc[g][1], ds.y, xin.y);
+      z[g][2] = fmaf(acc[g][2], ds.z, xin.z); z[g][3] = fmaf(acc[g][3], ds.w, xin.w);
+    }
+    h4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float cc = fmaf(rv_sigmoid(z[1][i]), c[i], rv_sigmoid(z[0][i]) * rv_tanh(z[2][i]));
+      const float hh = rv_sigmoid(z[3][i]) * rv_tanh(cc);
+      c[i] = cc; hl[i] = hh;
+      const float sv = hh * 16384.f;
+      hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]);
+    }
+    {
+      char* dst = hb + (cur ^ 1) * 8192 + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
+      *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
+    }
+    if (live)
+      *reinterpret_cast<float4*>(a.out + ((size_t)(b0 + n) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
+    if (F == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xc[g] = xn[g];
+    }
+    cur ^= 1;
+    RV_MX_BARRIER();
+  }
+  if (live) {
+    *reinterpret_cast<float4*>(a.hT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
+    *reinterpret_cast<float4*>(a.cT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(c[0], c[1], c[2], c[3]);
+  }
+}
+
+// x . W + b for a layer-0 encoder with a handful of input features (the event encoder: F = 5), both directions:
+// xw [B*T, 2, 512].  One thread = 4 gate columns of one row; HBM-bound on its output (4 KB per chunk-timestep).
+template <int F>
+__global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ x, int rows, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ xw) {
+  const int c4 = threadIdx.x & 127, dir = threadIdx.x >> 7;
+  const float* W = dir ? W1 : W0;
+  const float* b = dir ? b1 : b0;
+  float4 wr[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) wr[f] = *reinterpret_cast<const float4*>(W + (size_t)f * RV_G + 4 * c4);
+  const float4 bv = *reinterpret_cast<const float4*>(b + 4 * c4);
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    float4 acc = bv;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const float xv = x[(size_t)r * F + f];
+      acc.x = fmaf(xv, wr[f].x, acc.x); acc.y = fmaf(xv, wr[f].y, acc.y); acc.z = fmaf(xv, wr[f].z, acc.z); acc.w = fmaf(xv, wr[f].w, acc.w);
+    }
+    *reinterpret_cast<float4*>(xw + ((size_t)r * 2 + dir) * RV_G + 4 * c4) = acc;
+  }
+}
+
+constexpr size_t mx_lds_bytes(int F, int T) { return 16384 + sizeof(float) * (3 * RV_G + (F == 1 ? (size_t)RV_MX_ROWS * T : 0)); }
+
+}  // namespace
+
+bool lstm_rec_mx_window_fits(int T) { return mx_lds_bytes(1, T) <= 160 * 1024; }
+
+hipError_t configure_mx_kernels() {
+  hipError_t first = hipSuccess;
+  for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_mx<0>), reinterpret_cast<const void*>(&k_lstm_rec_mx<1>)}) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  }
+  return first;
+}
+
+void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s) {
+  dim3 grid((a.B + RV_MX_ROWS - 1) / RV_MX_ROWS, 2);
+  if (F == 1) hipLaunchKernelGGL((k_lstm_rec_mx<1>), grid, dim3(512), mx_lds_bytes(1, a.T), s, a);
+  else hipLaunchKernelGGL((k_lstm_rec_mx<0>), grid, dim3(512), mx_lds_bytes(0, a.T), s, a);
+}
+
+void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw, hipStream_t s) {
+  const int grid = rows < 4096 ? rows : 4096;
+  if (F == 5) hipLaunchKernelGGL((k_inproj_small<5>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw);
+  else hipLaunchKernelGGL((k_inproj_small<1>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw);
+}

@@ -23,6 +23,8 @@ struct LstmW { const float *W, *U, *b; };
 
 struct ProfEntry { double ms = 0; int64_t n = 0; };
 
+constexpr int RV_MAX_ASYNC = 8;
+
 struct GraphKey {
   int B, W, Tm, L, greedy, taps, split;
   bool operator<(const GraphKey& o) const {
@@ -62,6 +64,12 @@ struct RvContext {
   int opt_split_proj = 2;                   // fused projection on split-bf16 MFMAs (six part products, f32-equivalent); 0 = f32 MFMAs
   int opt_mx_att = 1;                       // persistent decode (Luong, one cell): attention on the matrix pipe
   float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
+  uint16_t* d_Ua = nullptr;                 // derived: recurrent kernels as MFMA A fragments (two f16 parts) + row factors, [enc][layer][dir][RV_UA_SLOT]
+  uint16_t* d_Wx16 = nullptr;               // derived: input kernels of encoder layers >= 1, both directions, as the split GEMM's B slabs, [enc][layer-1][RV_WX16_SLOT]
+  float* d_bx2 = nullptr;                   // derived: [b_fwd | b_bwd] of those layers, [enc][layer-1][1024]
+  int opt_wide = 1;                         // matrix-pipe recurrence, 16 chunks per workgroup: 1 on (default: every call runs the same kernels whatever its slab
+                                            // size, so results do not depend on how a read is cut into slabs / shards), 0 packed-FMA kernels, -1 per-call choice
+  int lwide = 0;
   int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
@@ -105,6 +113,15 @@ struct RvContext {
 
   // last call
   int lB = 0, lW = 0, lTm = 0, lL = 0, lS = 0, lgreedy = 0, ltaps = 0;
+
+  // asynchronous calls (rv_beam_search_submit* / rv_beam_search_collect*): the handle owns `kids` more slab contexts -- own stream,
+  // own buffers, the PARENT's weights and derived images -- so that several slabs are in flight on the GPU at once
+  RvContext* parent = nullptr;
+  std::vector<RvContext*> kids;
+  int opt_async_depth = 2;                  // contexts the asynchronous entry points rotate through (1..RV_MAX_ASYNC)
+  int inflight_hint = 1;                    // slabs the caller keeps in flight (1 for the synchronous entry points): sizes the workgroups
+  int next_slot = 0, generation = 0;
+  struct PendingCall { bool busy = false, trivial = false, greedy = false, dev_out = false, calls = false; int B = 0, steps = 0, V = 0, Wd = 0, ticket = -1; } pend;
 };
 
 namespace {
@@ -216,15 +233,26 @@ struct Scope {
 };
 
 void drain_profile(RvContext* h) {
+  RvContext* root = h->parent ? h->parent : h;
   for (auto& p : h->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-      ProfEntry& e = h->prof[p.name];
+      ProfEntry& e = root->prof[p.name];
       e.ms += ms; e.n += 1;
     }
     h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
   }
   h->pending.clear();
+}
+
+// Side stream g of a context, created on first use.  Highest priority: their few workgroups should take CU slots as soon as they free up.
+hipStream_t side_stream(RvContext* h, int g) {
+  if (!h->side[g]) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->side[g], hipStreamNonBlocking, hi) != hipSuccess) { h->side[g] = nullptr; return h->stream; }   // (degrades to in-order)
+  }
+  return h->side[g];
 }
 
 int pick_rows_per_block(int B) {
@@ -236,6 +264,17 @@ int pick_rows_per_block(int B) {
 }
 
 // Encoder.call for one encoder (basecaller.py:48-59) writing into enc_out at time offset t_off.
+// Does this slab run its encoder recurrences on the matrix pipe (lstm_mx.hip: 16 chunks of one direction per workgroup)?
+bool wide_recurrence(const RvContext* h, int B, int T_r) {
+  if (h->opt_wide == 0 || !h->opt_fuse) return false;
+  if (h->cfg.mode != RV_MODE_EVENT && !lstm_rec_mx_window_fits(T_r)) return false;
+  if (h->opt_wide > 0) return true;
+  // the packed-FMA kernels cost per row, the matrix form per workgroup: it pays once the slabs in flight together give the
+  // FMA kernels 4 rows per workgroup (one slab of > 256 chunks, or two 256-chunk slabs in flight through the asynchronous calls;
+  // measured at T = 300 + 30: 512 chunks 185 k -> 199 k chunks/s, two slabs of 256 in flight 200 k -> 218 k)
+  return pick_rows_per_block(B * std::max(h->inflight_hint, 1)) >= 4;
+}
+
 void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s,
                  int l_begin = 0, int l_end = 1 << 30) {
   const int depth = h->cfg.enc_depth;
@@ -251,10 +290,35 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       const LstmW& w = h->enc[e][l][dr];
       a.U[dr] = w.U;
       a.Up[dr] = h->d_Up + ((size_t)(e * depth + l) * 2 + dr) * RV_U * RV_G;
+      a.Ua[dr] = h->d_Ua + ((size_t)(e * depth + l) * 2 + dr) * RV_UA_SLOT;
       a.h0[dr] = l > 0 ? h->st[e][rd][2 * dr] : nullptr;
       a.c0[dr] = l > 0 ? h->st[e][rd][2 * dr + 1] : nullptr;
       a.hT[dr] = h->st[e][wr][2 * dr];
       a.cT[dr] = h->st[e][wr][2 * dr + 1];
+    }
+    if (h->lwide) {
+      // matrix-pipe recurrence.  Raw layer 0 folds its one-feature input projection in; every other layer reads pre-projected
+      // inputs xw [B,T,2,512]: event layer 0 from a small elementwise kernel, layers >= 1 from the split-f16 GEMM (both directions
+      // and their biases in one launch, A read once).
+      if (l == 0 && F == 1) {
+        a.x = x;
+        for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
+        Scope sc(h, "lstm_rec_raw_l0", s);
+        launch_lstm_rec_mx(a, 1, s);
+        continue;
+      }
+      if (l == 0) {
+        Scope sc(h, e == 0 ? "inproj_raw_l0" : "inproj_event_l0", s);
+        launch_inproj_small(x, B * T, F, h->enc[e][0][0].W, h->enc[e][0][0].b, h->enc[e][0][1].W, h->enc[e][0][1].b, h->xw[e], s);
+      } else {
+        Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event", s);
+        launch_gemm_split_blocks(h->act[e][(l - 1) & 1], B * T, h->d_Wx16 + (size_t)(e * (depth - 1) + (l - 1)) * RV_WX16_SLOT, 4,
+                                 h->d_bx2 + (size_t)(e * (depth - 1) + (l - 1)) * 2 * RV_G, h->xw[e], 2 * RV_G, s);
+      }
+      a.x = h->xw[e];
+      Scope sc(h, l == 0 ? "lstm_rec_event_l0" : (e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p"), s);
+      launch_lstm_rec_mx(a, 0, s);
+      continue;
     }
     if (l == 0) {
       a.x = x;
@@ -319,10 +383,15 @@ void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool pr
 
 struct CallsOut { const uint8_t* lut; uint8_t* bases; int32_t* lengths; float* probs; };
 
-int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W,
-        int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, int32_t* S_out, const CallsOut* calls = nullptr) {
+// Everything of a call up to (not including) the wait for the stream: launches and the D2H copies into pinned staging.
+// dev_out: tokens / out2 are device pointers written by the finalize kernel; else the results wait in pinned memory for finish().
+// lut != nullptr: the fused post-processing (rv_beam_search_calls) instead of tokens / scores.
+int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W,
+            int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, const uint8_t* lut) {
   if (!h) return RV_EINVAL;
   const RvConfig& c = h->cfg;
+  const bool calls = lut != nullptr;
+  if (h->pend.busy) return fail(h, RV_ESTATE, "this context still holds an uncollected call");
   if (!h->loaded) return fail(h, RV_ESTATE, "no weights loaded (call rv_load_weights first)");
   const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
   if (!use_raw) T_r = 0;
@@ -335,12 +404,13 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   if ((use_raw && !raw) || (use_ev && !ev)) return fail(h, RV_EINVAL, "missing input pointer for this mode");
   if (T_r + T_e > 352) return fail(h, RV_EUNSUPPORTED, "attention memory of %d steps exceeds the 352 the decode kernel is built for", T_r + T_e);
   if (L > 64) return fail(h, RV_EUNSUPPORTED, "max_output_len %d exceeds 64", L);
-  if (!S_out || (B > 0 && L > 1 && !calls && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
-  if (calls && (!calls->lut || !calls->bases || !calls->lengths || !calls->probs)) return fail(h, RV_EINVAL, "null calls output pointer");
+  if (dev_out && B > 0 && L > 1 && (!tokens || !out2)) return fail(h, RV_EINVAL, "null output pointer");
   HIPCHK(h, hipSetDevice(c.device));
   h->lB = B; h->lW = W; h->lL = L; h->lS = 0; h->lgreedy = greedy; h->lTm = T_r + T_e; h->ltaps = h->opt_taps; h->lptaps = h->opt_ptaps;
-  *S_out = 0;
-  if (B == 0 || L <= 1) return RV_OK;
+  h->pend = RvContext::PendingCall{};
+  h->pend.busy = true; h->pend.greedy = greedy; h->pend.dev_out = dev_out; h->pend.calls = calls;
+  h->pend.B = B; h->pend.steps = std::max(L - 1, 0); h->pend.V = c.vocab; h->pend.Wd = greedy ? 1 : W;
+  if (B == 0 || L <= 1) { h->pend.trivial = true; return RV_OK; }
 
   hipStream_t s = h->stream;
   const int Tm = T_r + T_e, V = c.vocab, steps = L - 1;
@@ -356,19 +426,22 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
   }
 
-  if (!h->opt_fuse && c.enc_depth > 1) {   // unfused path only: pre-projected tensors [max_batch, T_max, 2, 512], allocated on first use
-    if (use_raw && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
+  h->lwide = wide_recurrence(h, B, T_r) ? 1 : 0;
+  if ((!h->opt_fuse && c.enc_depth > 1) || h->lwide) {   // pre-projected tensors [max_batch, T_max, 2, 512] (unfused path, matrix-pipe recurrence), allocated on first use
+    if (use_raw && c.enc_depth > 1 && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
     if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
   }
   // ---- _encode_input (basecaller.py:395-416)
   // The mask is first read by the memory set-up / the decode: it runs on a side stream beside the encoders instead of in front
   // of them (profiling modes keep it on the main stream so that its events pair up).
-  const bool mask_aside = h->opt_profile == 0 || h->opt_profile == 3;
+  // (with several slabs in flight the other slabs fill the chip: one stream per context then, no fork / join)
+  const bool mask_aside = (h->opt_profile == 0 || h->opt_profile == 3) && h->inflight_hint <= 1 && !h->parent;
   if (mask_aside) {
+    hipStream_t sm = side_stream(h, 2);
     HIPCHK(h, hipEventRecord(h->ev_fork, s));
-    HIPCHK(h, hipStreamWaitEvent(h->side[2], h->ev_fork, 0));     // inputs (H2D copies on s) are in place
-    launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, h->side[2]);
-    HIPCHK(h, hipEventRecord(h->ev_join[2], h->side[2]));
+    HIPCHK(h, hipStreamWaitEvent(sm, h->ev_fork, 0));     // inputs (H2D copies on s) are in place
+    launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, sm);
+    HIPCHK(h, hipEventRecord(h->ev_join[2], sm));
   } else {
     Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s);
   }
@@ -378,7 +451,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     // raw layer 0 alone (every recurrence workgroup needs a whole CU); then the short event chain on a side stream
     // UNDER the raw encoder's input-projection GEMM: a recurrence workgroup (2 x 168 VGPRs per SIMD, VALU-bound) and a
     // GEMM workgroup (144 registers, MFMA-bound) fit on one CU together.
-    hipStream_t sev = h->side[0];
+    hipStream_t sev = side_stream(h, 0);
     run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 0, 1);
     HIPCHK(h, hipEventRecord(h->ev_fork, s));
     HIPCHK(h, hipStreamWaitEvent(sev, h->ev_fork, 0));
@@ -421,7 +494,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   d.call_bases = nullptr; d.call_probs = nullptr; d.call_len = nullptr;
   if (calls) {
     d.call_bases = h->d_bases; d.call_probs = h->d_probs; d.call_len = h->d_clen;
-    for (int v = 0; v < RV_MAX_VOCAB; ++v) d.lut[v] = v < V ? calls->lut[v] : 0;
+    for (int v = 0; v < RV_MAX_VOCAB; ++v) d.lut[v] = v < V ? lut[v] : 0;
   }
   const int N = B * d.W;
   if (h->opt_taps) {
@@ -478,14 +551,14 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     parts.nfin[g] = p.nfin; parts.B[g] = p.B;
     if (!h->lpersist) launch_dec_init(p, s);
   }
-  auto enqueue = [&](bool profiled) -> int {
+  auto enqueue_steps = [&](bool profiled) -> int {
     for (int g = 1; g < nsplit; ++g) {
       HIPCHK(h, hipEventRecord(h->ev_fork, s));
-      HIPCHK(h, hipStreamWaitEvent(h->side[g - 1], h->ev_fork, 0));
+      HIPCHK(h, hipStreamWaitEvent(side_stream(h, g - 1), h->ev_fork, 0));
     }
-    for (int g = 0; g < nsplit; ++g) launch_decode_steps(h, part[g], g == 0 ? s : h->side[g - 1], profiled && nsplit == 1);
+    for (int g = 0; g < nsplit; ++g) launch_decode_steps(h, part[g], g == 0 ? s : side_stream(h, g - 1), profiled && nsplit == 1);
     for (int g = 1; g < nsplit; ++g) {
-      HIPCHK(h, hipEventRecord(h->ev_join[g - 1], h->side[g - 1]));
+      HIPCHK(h, hipEventRecord(h->ev_join[g - 1], side_stream(h, g - 1)));
       HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[g - 1], 0));
     }
     return RV_OK;
@@ -519,7 +592,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
       }
       hipGraph_t graph = nullptr;
       HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue(false);
+      const int rc = enqueue_steps(false);
       hipError_t ce = hipStreamEndCapture(s, &graph);
       if (rc != RV_OK) return rc;
       HIPCHK(h, ce);
@@ -533,7 +606,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
   } else {
     if (h->opt_profile == 2) nsplit = 1, parts.n = 1;     // per-kernel events need one stream
     if (nsplit == 1) { part[0] = d; part[0].part = 0; part[0].nfin = d.nfin; parts.nfin[0] = d.nfin; parts.B[0] = B; launch_dec_init(part[0], s); }
-    const int rc = enqueue(h->opt_profile == 2);
+    const int rc = enqueue_steps(h->opt_profile == 2);
     if (rc != RV_OK) return rc;
   }
 
@@ -548,7 +621,7 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     }
   }
   HIPCHK(h, hipMemcpyAsync(h->pin_S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-  if (!dev_out && tokens) {
+  if (!dev_out && !calls) {
     HIPCHK(h, hipMemcpyAsync(h->pin_tok, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
   }
@@ -557,23 +630,146 @@ int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int
     HIPCHK(h, hipMemcpyAsync(h->pin_probs, h->d_probs, sizeof(float) * B * steps, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_clen, h->d_clen, sizeof(int) * B, hipMemcpyDeviceToHost, s));
   }
-  HIPCHK(h, hipStreamSynchronize(s));
+  h->lW = d.W;
+  return RV_OK;
+}
+
+// The rest of a call: wait for the context's stream, hand the staged results to the caller's host buffers.
+int finish(RvContext* h, int32_t* tokens, float* out2, const CallsOut* calls, int32_t* S_out) {
+  if (!h || !S_out) return RV_EINVAL;
+  if (!h->pend.busy) return fail(h, RV_ESTATE, "no call to collect on this context");
+  const RvContext::PendingCall p = h->pend;
+  h->pend.busy = false;
+  *S_out = 0;
+  if (p.trivial) return RV_OK;
+  if (!p.dev_out && !p.calls && (!tokens || !out2)) return fail(h, RV_EINVAL, "null output pointer");
+  if (p.calls && (!calls || !calls->bases || !calls->lengths || !calls->probs)) return fail(h, RV_EINVAL, "null calls output pointer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
   const int S = *h->pin_S;
-  if (!dev_out && tokens) {
+  const size_t B = p.B, steps = p.steps;
+  if (!p.dev_out && !p.calls) {
     memcpy(tokens, h->pin_tok, sizeof(int32_t) * B * steps);
-    memcpy(out2, h->pin_out2, sizeof(float) * B * steps * (greedy ? V : 1));
+    memcpy(out2, h->pin_out2, sizeof(float) * B * steps * (p.greedy ? p.V : 1));
   }
-  if (calls) {
-    memcpy(calls->bases, h->pin_bases, (size_t)B * steps);
+  if (p.calls) {
+    memcpy(calls->bases, h->pin_bases, B * steps);
     memcpy(calls->probs, h->pin_probs, sizeof(float) * B * steps);
     memcpy(calls->lengths, h->pin_clen, sizeof(int) * B);
   }
   drain_profile(h);
   *S_out = S;
   h->lS = S;
-  h->lW = d.W;
   return RV_OK;
+}
+
+int run(RvContext* h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W,
+        int L, bool greedy, int32_t* tokens, float* out2, bool dev_out, int32_t* S_out, const CallsOut* calls = nullptr) {
+  if (!h) return RV_EINVAL;
+  if (!S_out || (B > 0 && L > 1 && !calls && (!tokens || !out2))) return fail(h, RV_EINVAL, "null output pointer");
+  if (calls && (!calls->lut || !calls->bases || !calls->lengths || !calls->probs)) return fail(h, RV_EINVAL, "null calls output pointer");
+  *S_out = 0;
+  h->inflight_hint = 1;
+  const int rc = enqueue(h, raw, ev, dev_in, B, T_r, T_e, W, L, greedy, tokens, out2, dev_out, calls ? calls->lut : nullptr);
+  if (rc != RV_OK) { h->pend.busy = false; return rc; }
+  return finish(h, tokens, out2, calls, S_out);
+}
+
+
+// Per-slab working set of a context: inputs, activations, decoder state, outputs, staging, side streams.  Weights are not part of it
+// (child contexts of the asynchronous calls share their parent's).
+int alloc_slab_buffers(RvContext* h) {
+  const RvConfig& c = h->cfg;
+#define TRY(x) do { int r_ = (x); if (r_ != RV_OK) return r_; } while (0)
+#define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(h, RV_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+  const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
+  const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
+  const size_t Tm = Tr + Te, L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
+  TRY(dalloc(h, &h->d_raw, B * Tr));
+  TRY(dalloc(h, &h->d_ev, B * Te * 5));
+  TRY(dalloc(h, &h->mask, B * Tm));
+  const int npp = c.enc_depth > 2 ? 2 : (c.enc_depth > 1 ? 1 : 0);
+  for (int p = 0; p < npp; ++p) {
+    if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
+    if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
+  }
+  // (the pre-projected tensors xw of the unfused path -- 4 KB per chunk-timestep -- are allocated on first use: run_encoder)
+  for (int e = 0; e < 2; ++e)
+    for (int st = 0; st < 2; ++st)
+      for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
+  TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
+  TRY(dalloc(h, &h->keys, B * Tm * RV_U));
+  TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
+  DecState& d = h->dec_st;
+  if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
+  if (getenv("RV_REC_STAMPS")) { TRY(dalloc(h, &h->rec_ts, 24)); h->rec_ts_layer = atoi(getenv("RV_REC_STAMPS")) == 2 ? 1 : 0; }
+  if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
+  d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
+  TRY(dalloc(h, &d.xh, c.dec_depth * N * RV_E));
+  TRY(dalloc(h, &d.z, N * RV_G));
+  TRY(dalloc(h, &d.c, c.dec_depth * N * RV_U));
+  TRY(dalloc(h, &d.c_new, c.dec_depth * N * RV_U));
+  TRY(dalloc(h, &d.h_new, c.dec_depth * N * RV_U));
+  TRY(dalloc(h, &d.tok, N));
+  TRY(dalloc(h, &d.log_probs, N));
+  TRY(dalloc(h, &d.finished, N));
+  TRY(dalloc(h, &d.lengths, N));
+  TRY(dalloc(h, &d.step_ids, L * N));
+  TRY(dalloc(h, &d.parent_ids, L * N));
+  TRY(dalloc(h, &d.step_scores, L * N));
+  TRY(dalloc(h, &d.step_logits, L * N * V));
+  TRY(dalloc(h, &d.nfin, 4 * (L + 1)));
+  TRY(dalloc(h, &d.S_dev, 8));
+  TRY(dalloc(h, &h->d_chunk_steps, (size_t)c.max_batch));
+  // (side streams are created on first use -- side_stream(): the contexts of the asynchronous calls never need them, and every
+  //  stream of the process competes for the same few hardware queues)
+  for (int g = 0; g < 3; ++g) HIPTRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+  HIPTRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  if (const char* e = getenv("RV_DECODE_SPLIT")) h->opt_split = atoi(e);
+  TRY(dalloc(h, &h->out_tokens, B * L));
+  TRY(dalloc(h, &h->out2, B * L * V));
+  HIPTRY(hipHostMalloc((void**)&h->pin_raw, std::max<size_t>(B * Tr, 1) * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_ev, std::max<size_t>(B * Te * 5, 1) * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_tok, B * L * sizeof(int32_t), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_out2, B * L * V * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocDefault));
+  TRY(dalloc(h, &h->d_bases, B * L));
+  TRY(dalloc(h, &h->d_probs, B * L));
+  TRY(dalloc(h, &h->d_clen, B));
+  HIPTRY(hipHostMalloc((void**)&h->pin_bases, B * L, hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_probs, B * L * sizeof(float), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_clen, B * sizeof(int), hipHostMallocDefault));
+#undef TRY
+#undef HIPTRY
+  return RV_OK;
+}
+
+// A further slab context of handle p for the asynchronous calls: own stream and buffers, p's weights.
+int create_child(RvContext* p, RvContext** out) {
+  RvContext* h = new RvContext();
+  h->cfg = p->cfg;
+  h->parent = p;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(p, RV_EHIP, "hipStreamCreate failed for an asynchronous context"); }
+  h->d_w = p->d_w; h->n_w = p->n_w;
+  h->d_WmemT = p->d_WmemT; h->d_Up = p->d_Up; h->d_Wp = p->d_Wp; h->d_Wsb = p->d_Wsb; h->d_Wh = p->d_Wh; h->d_Ua = p->d_Ua;
+  h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16;
+  h->d_WcatT = p->d_WcatT;
+  bind_weights(h);
+  const int rc = alloc_slab_buffers(h);
+  if (rc != RV_OK) { p->err = h->err; rv_destroy(h); return rc; }
+  *out = h;
+  return RV_OK;
+}
+
+// options and weight-derived scalars of the parent, as of now
+void sync_child(RvContext* k, const RvContext* p) {
+  k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
+  k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
+  k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_tail_wave = p->opt_tail_wave;
+  k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
+  k->opt_taps = 0; k->opt_ptaps = 0;      // debug taps belong to the synchronous calls
+  k->inflight_hint = p->inflight_hint;
 }
 
 }  // namespace
@@ -622,9 +818,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   HIPTRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPTRY(configure_decode_kernels());    // a refused LDS opt-in would otherwise surface as an opaque launch error later
   HIPTRY(configure_rec_kernels());
-  const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
-  const size_t B = c.max_batch, Tr = use_raw ? c.max_raw_len : 0, Te = use_ev ? c.max_event_len : 0;
-  const size_t Tm = Tr + Te, L = c.max_output_len, N = B * c.max_beam, V = c.vocab;
+  HIPTRY(configure_mx_kernels());
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
@@ -633,71 +827,16 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
+  TRY(dalloc(h, &h->d_Ua, (size_t)2 * c.enc_depth * 2 * RV_UA_SLOT));
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wx16, (size_t)2 * (c.enc_depth - 1) * RV_WX16_SLOT));
+  if (c.enc_depth > 1) TRY(dalloc(h, &h->d_bx2, (size_t)2 * (c.enc_depth - 1) * 2 * RV_G));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wh, (size_t)2 * (c.enc_depth - 1) * 2 * RV_WH_SLOT));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wsb, (size_t)2 * (c.enc_depth - 1) * 2 * 3 * RV_E * RV_G));
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
-  TRY(dalloc(h, &h->d_raw, B * Tr));
-  TRY(dalloc(h, &h->d_ev, B * Te * 5));
-  TRY(dalloc(h, &h->mask, B * Tm));
-  const int npp = c.enc_depth > 2 ? 2 : (c.enc_depth > 1 ? 1 : 0);
-  for (int p = 0; p < npp; ++p) {
-    if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
-    if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
-  }
-  // (the pre-projected tensors xw of the unfused path -- 4 KB per chunk-timestep -- are allocated on first use: run_encoder)
-  for (int e = 0; e < 2; ++e)
-    for (int st = 0; st < 2; ++st)
-      for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
-  TRY(dalloc(h, &h->enc_out, B * Tm * RV_E));
-  TRY(dalloc(h, &h->keys, B * Tm * RV_U));
-  TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
-  DecState& d = h->dec_st;
-  if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
-  if (getenv("RV_REC_STAMPS")) { TRY(dalloc(h, &h->rec_ts, 24)); h->rec_ts_layer = atoi(getenv("RV_REC_STAMPS")) == 2 ? 1 : 0; }
-  if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
-  d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
-  TRY(dalloc(h, &d.xh, c.dec_depth * N * RV_E));
-  TRY(dalloc(h, &d.z, N * RV_G));
-  TRY(dalloc(h, &d.c, c.dec_depth * N * RV_U));
-  TRY(dalloc(h, &d.c_new, c.dec_depth * N * RV_U));
-  TRY(dalloc(h, &d.h_new, c.dec_depth * N * RV_U));
-  TRY(dalloc(h, &d.tok, N));
-  TRY(dalloc(h, &d.log_probs, N));
-  TRY(dalloc(h, &d.finished, N));
-  TRY(dalloc(h, &d.lengths, N));
-  TRY(dalloc(h, &d.step_ids, L * N));
-  TRY(dalloc(h, &d.parent_ids, L * N));
-  TRY(dalloc(h, &d.step_scores, L * N));
-  TRY(dalloc(h, &d.step_logits, L * N * V));
-  TRY(dalloc(h, &d.nfin, 4 * (L + 1)));
-  TRY(dalloc(h, &d.S_dev, 8));
-  TRY(dalloc(h, &h->d_chunk_steps, (size_t)c.max_batch));
-  for (int g = 0; g < 3; ++g) {
-    {   // side streams get the highest priority: their few workgroups should take CU slots as soon as they free up
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      HIPTRY(hipStreamCreateWithPriority(&h->side[g], hipStreamNonBlocking, hi));
-    }
-    HIPTRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
-  }
-  HIPTRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  if (const char* e = getenv("RV_DECODE_SPLIT")) h->opt_split = atoi(e);
-  TRY(dalloc(h, &h->out_tokens, B * L));
-  TRY(dalloc(h, &h->out2, B * L * V));
-  HIPTRY(hipHostMalloc((void**)&h->pin_raw, std::max<size_t>(B * Tr, 1) * sizeof(float), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_ev, std::max<size_t>(B * Te * 5, 1) * sizeof(float), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_tok, B * L * sizeof(int32_t), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_out2, B * L * V * sizeof(float), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocDefault));
-  TRY(dalloc(h, &h->d_bases, B * L));
-  TRY(dalloc(h, &h->d_probs, B * L));
-  TRY(dalloc(h, &h->d_clen, B));
-  HIPTRY(hipHostMalloc((void**)&h->pin_bases, B * L, hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_probs, B * L * sizeof(float), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_clen, B * sizeof(int), hipHostMallocDefault));
+  TRY(alloc_slab_buffers(h));
 #undef TRY
 #undef HIPTRY
   *out = h;
@@ -706,6 +845,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
 
 void rv_destroy(rv_handle h) {
   if (!h) return;
+  for (RvContext* k : h->kids) rv_destroy(k);
+  h->kids.clear();
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
@@ -726,6 +867,8 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
   if (!h) return RV_EINVAL;
   if (!blob) return fail(h, RV_EINVAL, "null weight blob");
   if (n_floats != h->n_w) return fail(h, RV_EINVAL, "weight blob has %zu floats, config needs %zu", n_floats, h->n_w);
+  if (h->pend.busy) return fail(h, RV_ESTATE, "collect the calls in flight before loading weights");
+  for (RvContext* k : h->kids) if (k->pend.busy) return fail(h, RV_ESTATE, "collect the calls in flight before loading weights");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpyAsync(h->d_w, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
   {   // derived layout for the decoder cell kernel: the input-kernel rows that multiply a dense input
@@ -753,6 +896,72 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           float* dst = h->d_Up + ((size_t)(e * h->cfg.enc_depth + l) * 2 + dr) * RV_U * RV_G;
           HIPCHK(h, hipMemcpy(dst, up.data(), up.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+    // ... and as MFMA A fragments of U^T for the matrix-pipe recurrence: wave w, gate g, k-step ks, part p, lane (m = lane%16, kq = lane/16)
+    // holds s_r U[32 ks + 8 kq + j][r], r = 128 g + 16 w + m (s_r: power of two, the column's largest element into [2^13, 2^14))
+    for (int e = 0; e < 2; ++e)
+      for (int l = 0; l < h->cfg.enc_depth; ++l)
+        for (int dr = 0; dr < 2; ++dr) {
+          const size_t off = (size_t)(h->enc[e][l][dr].U - h->d_w);
+          std::vector<uint16_t> ua(RV_UA_SLOT);
+          float cs[RV_G];
+          for (int r = 0; r < RV_G; ++r) {
+            float mx = 0.f;
+            for (int k = 0; k < RV_U; ++k) mx = std::max(mx, std::fabs(blob[off + (size_t)k * RV_G + r]));
+            int ex = 0;
+            if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);
+            cs[r] = std::ldexp(1.0f, 14 - ex);
+          }
+          for (int w = 0; w < 8; ++w)
+            for (int g = 0; g < 4; ++g)
+              for (int ks = 0; ks < 4; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                  for (int j = 0; j < 8; ++j) {
+                    const int r = g * RV_U + 16 * w + (ln & 15);
+                    const float v = blob[off + (size_t)(32 * ks + 8 * (ln >> 4) + j) * RV_G + r] * cs[r];   // exact
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                    const size_t base = ((((size_t)w * 4 + g) * 4 + ks) * 2) * 64 * 8;
+                    ua[base + (size_t)ln * 8 + j] = hb;
+                    ua[base + 64 * 8 + (size_t)ln * 8 + j] = lb;
+                  }
+          for (int r = 0; r < RV_G; ++r) { const float f = std::ldexp(1.0f, -14) / cs[r]; memcpy(&ua[(size_t)2 * RV_U * RV_G + 2 * r], &f, 4); }
+          HIPCHK(h, hipMemcpy(h->d_Ua + ((size_t)(e * h->cfg.enc_depth + l) * 2 + dr) * RV_UA_SLOT, ua.data(), ua.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+    // encoder layers >= 1, both directions' input kernels as the split GEMM's B slabs: column block cb = 2 dir + half holds columns
+    // 256 half .. of direction dir; [cb][8 k-steps][16 tiles][2 parts][64 lanes][8 f16] of the column-scaled kernel, then 1024 factors
+    for (int e = 0; e < 2; ++e)
+      for (int l = 1; l < h->cfg.enc_depth; ++l) {
+        std::vector<uint16_t> img(RV_WX16_SLOT);
+        std::vector<float> b2(2 * RV_G);
+        for (int dr = 0; dr < 2; ++dr) {
+          const size_t off = (size_t)(h->enc[e][l][dr].W - h->d_w), boff = (size_t)(h->enc[e][l][dr].b - h->d_w);
+          for (int n = 0; n < RV_G; ++n) b2[(size_t)dr * RV_G + n] = blob[boff + n];
+          for (int n = 0; n < RV_G; ++n) {
+            float mx = 0.f;
+            for (int k = 0; k < RV_E; ++k) mx = std::max(mx, std::fabs(blob[off + (size_t)k * RV_G + n]));
+            int ex = 0;
+            if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);
+            const float sc = std::ldexp(1.0f, 14 - ex);
+            const int cb = 2 * dr + n / RV_E, nn = n % RV_E;
+            const float f = std::ldexp(1.0f, -14) / sc;
+            memcpy(&img[(size_t)4 * 2 * RV_E * RV_E + 2 * ((size_t)cb * RV_E + nn)], &f, 4);
+            for (int k = 0; k < RV_E; ++k) {
+              const float v = blob[off + (size_t)k * RV_G + n] * sc;
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+              const int ks = k / 32, ln = 16 * ((k % 32) / 8) + (nn % 16), j = k % 8, nt = nn / 16;
+              const size_t base = (size_t)cb * 2 * RV_E * RV_E + ((((size_t)ks * 16 + nt) * 2) * 64) * 8;
+              img[base + (size_t)ln * 8 + j] = hb;
+              img[base + 64 * 8 + (size_t)ln * 8 + j] = lb;
+            }
+          }
+        }
+        const size_t slot = (size_t)(e * (h->cfg.enc_depth - 1) + (l - 1));
+        HIPCHK(h, hipMemcpy(h->d_Wx16 + slot * RV_WX16_SLOT, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_bx2 + slot * 2 * RV_G, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     // encoder layers >= 1: W [256][512] -> [32 column tiles][16 k-groups][64 lanes][4]: lane (q = lane/16, col = lane%16)
     // of tile nt finds W[16 g + 4 i + q][16 nt + col] for its 4 MFMAs i of k-group g in one float4 (lstm_rec.hip)
     for (int e = 0; e < 2; ++e)
@@ -907,6 +1116,69 @@ int rv_greedy_search_dev(rv_handle h, const float* raw, const float* event, int3
   return run(h, raw, event, true, B, T_r, T_e, 1, L, true, tokens, logits, true, S_out);
 }
 
+// ---- asynchronous calls: submit returns once the slab's work is queued on one of the handle's contexts; collect waits for it.
+static int submit(rv_handle h, const float* raw, const float* ev, bool dev_in, int B, int T_r, int T_e, int W, int L,
+                  int32_t* tokens, float* out2, bool dev_out, const uint8_t* lut, int32_t* ticket) {
+  if (!h || !ticket) return RV_EINVAL;
+  *ticket = -1;
+  const int depth = std::min(std::max(h->opt_async_depth, 1), RV_MAX_ASYNC);
+  while ((int)h->kids.size() < depth - 1) {
+    RvContext* k = nullptr;
+    const int rc = create_child(h, &k);
+    if (rc != RV_OK) return rc;
+    h->kids.push_back(k);
+  }
+  RvContext* ctx = nullptr; int slot = -1;
+  for (int i = 0; i < depth && !ctx; ++i) {          // round robin over the idle contexts
+    const int sidx = (h->next_slot + i) % depth;
+    RvContext* cand = sidx == 0 ? h : h->kids[sidx - 1];
+    if (!cand->pend.busy) { ctx = cand; slot = sidx; }
+  }
+  if (!ctx) return fail(h, RV_ESTATE, "all %d asynchronous contexts hold uncollected calls (option async_depth): collect one first", depth);
+  h->inflight_hint = depth;
+  if (ctx != h) sync_child(ctx, h);
+  const int rc = enqueue(ctx, raw, ev, dev_in, B, T_r, T_e, W, L, false, tokens, out2, dev_out, lut);
+  if (rc != RV_OK) { ctx->pend.busy = false; if (ctx != h) h->err = ctx->err; return rc; }
+  h->next_slot = (slot + 1) % depth;
+  h->generation = (h->generation + 1) & 0xFFFFF;
+  ctx->pend.ticket = (h->generation << 4) | slot;
+  *ticket = ctx->pend.ticket;
+  return RV_OK;
+}
+static int collect(rv_handle h, int32_t ticket, int32_t* tokens, float* out2, const CallsOut* calls, int32_t* S_out) {
+  if (!h || !S_out) return RV_EINVAL;
+  const int slot = ticket & 15;
+  if (ticket < 0 || slot > (int)h->kids.size()) return fail(h, RV_EINVAL, "unknown ticket %d", ticket);
+  RvContext* ctx = slot == 0 ? h : h->kids[slot - 1];
+  if (!ctx->pend.busy || ctx->pend.ticket != ticket) return fail(h, RV_ESTATE, "ticket %d is not in flight (collected already?)", ticket);
+  const int rc = finish(ctx, tokens, out2, calls, S_out);
+  if (rc != RV_OK && ctx != h) h->err = ctx->err;
+  return rc;
+}
+int rv_beam_search_submit(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e, int32_t W, int32_t L,
+                          int32_t* ticket) {
+  return submit(h, raw, event, false, B, T_r, T_e, W, L, nullptr, nullptr, false, nullptr, ticket);
+}
+int rv_beam_search_collect(rv_handle h, int32_t ticket, int32_t* tokens, float* scores, int32_t* S_out) {
+  return collect(h, ticket, tokens, scores, nullptr, S_out);
+}
+int rv_beam_search_submit_dev(rv_handle h, const float* d_raw, const float* d_event, int32_t B, int32_t T_r, int32_t T_e, int32_t W,
+                              int32_t L, int32_t* d_tokens, float* d_scores, int32_t* ticket) {
+  return submit(h, d_raw, d_event, true, B, T_r, T_e, W, L, d_tokens, d_scores, true, nullptr, ticket);
+}
+int rv_beam_search_collect_dev(rv_handle h, int32_t ticket, int32_t* S_out) {
+  return collect(h, ticket, nullptr, nullptr, nullptr, S_out);
+}
+int rv_beam_search_submit_calls(rv_handle h, const float* raw, const float* event, int32_t B, int32_t T_r, int32_t T_e, int32_t W,
+                                int32_t L, const uint8_t* lut, int32_t* ticket) {
+  if (!lut) return h ? fail(h, RV_EINVAL, "null lut") : RV_EINVAL;
+  return submit(h, raw, event, false, B, T_r, T_e, W, L, nullptr, nullptr, false, lut, ticket);
+}
+int rv_beam_search_collect_calls(rv_handle h, int32_t ticket, uint8_t* bases, int32_t* lengths, float* probs, int32_t* S_out) {
+  const CallsOut c{nullptr, bases, lengths, probs};
+  return collect(h, ticket, nullptr, nullptr, &c, S_out);
+}
+
 int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!h || !key) return RV_EINVAL;
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
@@ -917,6 +1189,11 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
+  else if (!strcmp(key, "wide_recurrence")) h->opt_wide = value < 0 ? -1 : (value != 0);
+  else if (!strcmp(key, "async_depth")) {
+    if (value < 1 || value > RV_MAX_ASYNC) return fail(h, RV_EINVAL, "async_depth must be 1..%d", RV_MAX_ASYNC);
+    h->opt_async_depth = value;
+  }
   else if (!strcmp(key, "matrix_attention")) h->opt_mx_att = value != 0;
   else if (!strcmp(key, "split_projection")) h->opt_split_proj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(key, "attend_threads")) {

@@ -106,12 +106,14 @@ def _decode_shard(basecaller, raw, event, lo, hi, beam_width, max_output_len, sl
     steps = max(int(max_output_len) - 1, 0)
     end_token = int(basecaller.output_end_token)
     slab = int(slab) if slab else max(hi - lo, 1)
-    parts = []
-    for a in range(lo, hi, slab):
-        b = min(a + slab, hi)
+    def cut(a, b):
         pick = lambda x: None if x is None else x[a:b]
-        inp = {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
-        parts.append(basecaller.beam_search_prediction(inp, beam_width=beam_width, max_output_len=max_output_len))
+        return {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
+    cuts = [(a, min(a + slab, hi)) for a in range(lo, hi, slab)]
+    if len(cuts) > 1 and hasattr(basecaller, "beam_search_stream"):      # the shard's slabs in flight together (identical results)
+        parts = list(basecaller.beam_search_stream((cut(a, b) for a, b in cuts), beam_width, max_output_len))
+    else:
+        parts = [basecaller.beam_search_prediction(cut(a, b), beam_width=beam_width, max_output_len=max_output_len) for a, b in cuts]
     if len(parts) == 1:
         tok, sc = parts[0]
         return tok, sc, tok.shape[1]
@@ -145,6 +147,43 @@ def sharded_beam_search(basecaller, raw, event, beam_width: int, max_output_len:
     dev = getattr(basecaller, "device", None) if dist.get_backend(group) == "nccl" else None
     return gather_calls(tok, sc, S, n, max(int(max_output_len) - 1, 0),
                         end_token=int(basecaller.output_end_token), group=group, device=dev)
+
+
+def sharded_beam_search_stream(basecaller, slabs, beam_width: int, max_output_len: int, group=None, slab: int | None = None):
+    """Generator over an iterable of FULL slabs (raw, event): every rank decodes its shard of slab k + 1 (asynchronous calls) while
+    slab k's results are gathered -- the pipelined form of a loop over `sharded_beam_search`, one collective per slab, identical
+    results.  Shards larger than `slab` (or than the handle's max_batch) fall back to the slab-at-a-time form."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    steps = max(int(max_output_len) - 1, 0)
+    end_token = int(basecaller.output_end_token)
+    dev = getattr(basecaller, "device", None) if dist.get_backend(group) == "nccl" else None
+    depth = max(int(getattr(basecaller, "async_depth", 2)), 1)
+    mode = basecaller.input_data_type
+    queue = []
+
+    def finish(item):
+        call, n = item
+        if call is None:
+            tok, sc = torch.zeros((0, 0), dtype=torch.int32), torch.zeros((0, 0))
+        else:
+            tok, sc = basecaller.collect(call)
+        return gather_calls(tok, sc, tok.shape[1], n, steps, end_token=end_token, group=group, device=dev)
+
+    for raw, event in slabs:
+        n = (raw if raw is not None else event).shape[0]
+        lo, hi = shard_range(n, rank, world)
+        if not hasattr(basecaller, "submit_beam_search") or (slab and hi - lo > slab):
+            while queue:
+                yield finish(queue.pop(0))
+            yield sharded_beam_search(basecaller, raw, event, beam_width, max_output_len, group=group, slab=slab)
+            continue
+        if len(queue) >= depth:
+            yield finish(queue.pop(0))
+        pick = lambda x: None if x is None else x[lo:hi]
+        inp = {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
+        queue.append((basecaller.submit_beam_search(inp, beam_width, max_output_len) if hi > lo else None, n))
+    while queue:
+        yield finish(queue.pop(0))
 
 
 def pack_call_arrays(bases, probs, lens, n_total: int, max_steps: int, world: int):

@@ -25,9 +25,9 @@ class PerformanceEvaluator:
         # True: slab k is stitched on a host thread (rv_merger_append) while the GPU decodes slab k+1; implies the
         # fused post-processing.  t_merge is then the part of the merge the GPU work did not hide.
         self.pipelined_merge = pipelined_merge
-        # > 1 (with pipelined_merge): that many handles (`Basecaller.clone`) decode consecutive slabs at the same time, each from
-        # its own host thread: slab k + 1's encoders fill the CUs slab k's decode leaves as its chunks finish, and no launch gap or
-        # host copy leaves the GPU idle.  Results are identical (slabs are independent); t_predicting is then wall time.
+        # > 1: at least that many slabs in flight on the handle's contexts (Basecaller.set_async_depth; the default depth of 2
+        # applies otherwise): slab k + 1's encoders fill the CUs slab k's decode leaves as its chunks finish, and no launch gap
+        # or host copy leaves the GPU idle.  Results are identical (slabs are independent).
         self.concurrent_slabs = max(1, int(concurrent_slabs))
         self._clones = []
 
@@ -80,22 +80,34 @@ class PerformanceEvaluator:
         if self.pipelined_merge:
             return self._run_pipelined(data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width,
                                        t_data_loading)
-        for data in data_chunks:
+        # The reference decodes slab k, post-processes it, then decodes slab k + 1 (ravvent_performance_evaluator.py:51-70).  Here the
+        # slabs go through the asynchronous calls (Basecaller.beam_search_stream: identical results): slab k + 1 is already on the
+        # GPU while slab k is post-processed on the host.  t_predicting = the time this loop waits for the GPU.
+        unpacked = [utils.unpack_data_to_input_target(data, self.basecaller.input_data_type) for data in data_chunks]
+        L = unpacked[0][1].shape[1] if unpacked else 0
+        stream_ok = hasattr(self.basecaller, "beam_search_stream") and all(t.shape[1] == L for _, t in unpacked)
+        if stream_ok:
+            results = self.basecaller.beam_search_stream((inp for inp, _ in unpacked), beam_width, L, calls=self.fused_postprocessing)
+        elif self.fused_postprocessing:
+            results = (self.basecaller.beam_search_call_arrays(inp, beam_width=beam_width, max_output_len=t.shape[1]) for inp, t in unpacked)
+        else:
+            results = (self.basecaller.beam_search_prediction(inp, beam_width=beam_width, max_output_len=t.shape[1]) for inp, t in unpacked)
+        while True:
             start = timer()
-            input_data, target_data = utils.unpack_data_to_input_target(data, self.basecaller.input_data_type)
-            if self.fused_postprocessing:
-                seqs, probs = self.basecaller.beam_search_calls(input_data, beam_width=beam_width,
-                                                                max_output_len=target_data.shape[1])
-                t_predicting += timer() - start
-                nuc_preds.extend((seq, list(pr)) for seq, pr in zip(seqs, probs))
-                continue
-            pred_tokens, beam_scores = self.basecaller.beam_search_prediction(
-                input_data, beam_width=beam_width, max_output_len=target_data.shape[1])
+            res = next(results, None)
             t_predicting += timer() - start
+            if res is None:
+                break
             start = timer()
-            scores = utils.calc_prob_logits_beam_search_scores(beam_scores).numpy()
-            seqs = self.basecaller.tokens_to_nuc_sequences(pred_tokens)
-            nuc_preds.extend((seq, list(sc[:len(seq)])) for seq, sc in zip(seqs, scores))
+            if self.fused_postprocessing:
+                bases, probs, lens = res
+                flat, steps = bases.tobytes(), bases.shape[1]
+                nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), list(probs[i, :int(n)])) for i, n in enumerate(lens))
+            else:
+                pred_tokens, beam_scores = res
+                scores = utils.calc_prob_logits_beam_search_scores(beam_scores).numpy()
+                seqs = self.basecaller.tokens_to_nuc_sequences(pred_tokens)
+                nuc_preds.extend((seq, list(sc[:len(seq)])) for seq, sc in zip(seqs, scores))
             t_postprocessing += timer() - start
         start = timer()                # ravvent_performance_evaluator.py:73-75
         merged_seq = self.merger.merge([merger.SeqLogitsPair(seq, lg) for seq, lg in nuc_preds]).seq if nuc_preds else ""
@@ -173,48 +185,35 @@ class PerformanceEvaluator:
         bases = np.zeros((hi - lo, steps), np.uint8)
         probs = np.zeros((hi - lo, steps), np.float32)
         lens = np.zeros(hi - lo, np.int32)
-        for a in range(lo, hi, chunk_size):
-            b = min(a + chunk_size, hi)
-            x = {"joint": lambda: (raw_snippets[a:b], event_snippets[a:b]), "raw": lambda: raw_snippets[a:b],
-                 "event": lambda: event_snippets[a:b]}[mode]()
-            bs, pr, ln = self.basecaller.beam_search_call_arrays(x, beam_width=beam_width, max_output_len=max_output_len)
+        cuts = [(a, min(a + chunk_size, hi)) for a in range(lo, hi, chunk_size)]
+        pick = lambda a, b: {"joint": lambda: (raw_snippets[a:b], event_snippets[a:b]), "raw": lambda: raw_snippets[a:b],
+                             "event": lambda: event_snippets[a:b]}[mode]()
+        if hasattr(self.basecaller, "beam_search_stream"):     # slabs in flight on the handle's contexts (identical results)
+            results = self.basecaller.beam_search_stream((pick(a, b) for a, b in cuts), beam_width, max_output_len, calls=True)
+        else:
+            results = (self.basecaller.beam_search_call_arrays(pick(a, b), beam_width=beam_width, max_output_len=max_output_len) for a, b in cuts)
+        for (a, b), (bs, pr, ln) in zip(cuts, results):
             bases[a - lo:b - lo] = bs; probs[a - lo:b - lo] = pr; lens[a - lo:b - lo] = ln
         return bases, probs, lens
 
     def _run_pipelined(self, data_chunks, raw_snippets, event_snippets, bases_num, samples_num, beam_width, t_data_loading):
         from concurrent.futures import ThreadPoolExecutor
-        import queue
         sm = merger.StreamingMerger(self.merger.scores_id, self.merger.overlap_seq_len)
         kept, pending = [], []
-        t_predicting = 0.0
-        K = self.concurrent_slabs if hasattr(self.basecaller, "clone") else 1
-        while len(self._clones) < K - 1:
-            self._clones.append(self.basecaller.clone())
-        handles = queue.SimpleQueue()
-        for bc in [self.basecaller] + self._clones[:K - 1]:
-            handles.put(bc)
         mode = self.basecaller.input_data_type
-
-        def decode(data):
-            bc = handles.get()
-            try:
-                input_data, target_data = utils.unpack_data_to_input_target(data, mode)
-                return bc.beam_search_call_arrays(input_data, beam_width=beam_width, max_output_len=target_data.shape[1])
-            finally:
-                handles.put(bc)
-        with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=K) as gpu_pool:   # merge worker: slabs appended in read order
+        if self.concurrent_slabs > 1 and hasattr(self.basecaller, "set_async_depth"):
+            self.basecaller.set_async_depth(max(self.concurrent_slabs, getattr(self.basecaller, "async_depth", 2)))
+        unpacked = [utils.unpack_data_to_input_target(data, mode) for data in data_chunks]
+        L = unpacked[0][1].shape[1] if unpacked else 0
+        if hasattr(self.basecaller, "beam_search_stream") and all(t.shape[1] == L for _, t in unpacked):
+            results = self.basecaller.beam_search_stream((inp for inp, _ in unpacked), beam_width, L, calls=True)
+        else:
+            results = (self.basecaller.beam_search_call_arrays(inp, beam_width=beam_width, max_output_len=t.shape[1]) for inp, t in unpacked)
+        with ThreadPoolExecutor(max_workers=1) as pool:          # merge worker: slabs appended in read order while the GPU decodes on
             start = timer()
-            if K == 1:
-                for data in data_chunks:
-                    arrays = decode(data)
-                    kept.append(arrays)
-                    pending.append(pool.submit(sm.append, *arrays))
-            else:
-                futs = [gpu_pool.submit(decode, data) for data in data_chunks]
-                for f in futs:                                   # in read order, as they complete
-                    arrays = f.result()
-                    kept.append(arrays)
-                    pending.append(pool.submit(sm.append, *arrays))
+            for arrays in results:
+                kept.append(arrays)
+                pending.append(pool.submit(sm.append, *arrays))
             t_predicting = timer() - start
             start = timer()
             for f in pending:
@@ -260,13 +259,16 @@ class PerformanceEvaluator:
         probs = np.zeros((total, max(L - 1, 1)), np.float32)
         lens = np.zeros(total, np.int32)
         t_predicting = 0.0
-        for b0 in range(0, total, chunk_size):
-            b1 = min(b0 + chunk_size, total)
-            start = timer()
-            x = (raw[b0:b1], ev[b0:b1]) if self.basecaller.input_data_type == "joint" else (raw[b0:b1] if raw is not None else ev[b0:b1])
-            bs, pr, ln = self.basecaller.beam_search_call_arrays(x, beam_width=beam_width, max_output_len=L)
+        cuts = [(b0, min(b0 + chunk_size, total)) for b0 in range(0, total, chunk_size)]
+        pick = lambda b0, b1: (raw[b0:b1], ev[b0:b1]) if self.basecaller.input_data_type == "joint" else (raw[b0:b1] if raw is not None else ev[b0:b1])
+        start = timer()
+        if hasattr(self.basecaller, "beam_search_stream"):
+            results = self.basecaller.beam_search_stream((pick(b0, b1) for b0, b1 in cuts), beam_width, L, calls=True)
+        else:
+            results = (self.basecaller.beam_search_call_arrays(pick(b0, b1), beam_width=beam_width, max_output_len=L) for b0, b1 in cuts)
+        for (b0, b1), (bs, pr, ln) in zip(cuts, results):
             bases[b0:b1, :bs.shape[1]] = bs; probs[b0:b1, :pr.shape[1]] = pr; lens[b0:b1] = ln
-            t_predicting += timer() - start
+        t_predicting += timer() - start
         start = timer()
 
         def merge_one(i):

@@ -142,7 +142,8 @@ def test_config5_long_read_two_real_ranks(rv):
     assert len(merged) > 0.5 * N_BASES and out["read"] == merged
     assert 3800 < out["chunks_local"] < 3900
     for key in ("host", "dev"):
-        assert out[key][0].shape == t.shape and (out[key][0] == t).all() and np.array_equal(out[key][1], s), key
+        bad = np.nonzero((out[key][0] != t).any(axis=1) | (out[key][1] != s).any(axis=1))[0] if out[key][0].shape == t.shape else None
+        assert out[key][0].shape == t.shape and bad.size == 0, (key, out[key][0].shape, t.shape, None if bad is None else (bad.size, bad[:12]))
 
 
 def test_rccl_gather_world_one(rv):
@@ -236,8 +237,11 @@ def test_split_operands_saturated_activations(rv, oracle):
     assert (np.abs(e64) > 1.0 - 2.0 ** -20).mean() > 0.3                  # the regime was reached
     wmp = np.concatenate([flat["W_mem"], flat["W_att"][128:384]], axis=1).astype(np.float64)
     err, merr = {}, {}
-    for split in (2, 0):
-        bc.set_option("split_projection", split)
+    for split in (2, 0, 3):
+        # 2 / 0: the packed-FMA recurrence with its fused projection on split-f16 / f32 MFMAs, the memory projection likewise;
+        # 3: the default path -- matrix-pipe recurrence (h itself a split-f16 operand at its bound) + split-f16 projection GEMM
+        bc.set_option("wide_recurrence", 1 if split == 3 else 0)
+        bc.set_option("split_projection", 2 if split == 3 else split)
         bc.beam_search_prediction((raw, ev), 3, 4)
         enc = bc.get_tensor("enc_output").reshape(B, Tr + Te, 256)
         assert np.isfinite(enc).all() and np.abs(enc).max() <= 1.0
@@ -246,10 +250,11 @@ def test_split_operands_saturated_activations(rv, oracle):
         mem = bc.get_tensor("projected_memory").reshape(B, Tr + Te, 256)
         merr[split] = float(np.abs(mem - ref).max() / np.abs(ref).max())
     twin = float(np.abs(e32 - e64).max())
-    print(f"saturated encoder: |enc_output - fp64| split-f16 {err[2]:.2e}, f32 MFMA {err[0]:.2e}, numpy fp32 twin {twin:.2e}; "
-          f"memory projection / range: split {merr[2]:.2e}, f32 {merr[0]:.2e}")
+    print(f"saturated encoder: |enc_output - fp64| matrix-pipe recurrence {err[3]:.2e}, FMA recurrence + split-f16 projection {err[2]:.2e}, "
+          f"+ f32 MFMA projection {err[0]:.2e}, numpy fp32 twin {twin:.2e}; memory projection / range: split {merr[2]:.2e}, f32 {merr[0]:.2e}")
     assert err[2] < TOL and err[2] <= 2.0 * err[0] + 1e-6, (err, twin)
-    assert merr[2] <= 1e-6 and merr[2] <= 1.5 * merr[0] + 2e-7, merr
+    assert err[3] < TOL and err[3] <= 2.0 * err[0] + 1e-6, (err, twin)
+    assert merr[2] <= 1e-6 and merr[3] <= 1e-6 and merr[2] <= 1.5 * merr[0] + 2e-7, merr
     bc.close()
 
 
@@ -266,7 +271,7 @@ def test_split_operands_adversarial_attention(rv, oracle):
     B, Tr, Te, W, L = 12, 120, 20, 5, 16
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=Tr, max_event_len=Te)
     flat = rv.weights.init_weights(bc.cfg, seed=13)
-    flat["W_mem"] *= 8.0; flat["W_att"] *= 8.0; flat["W_fc"] *= 0.125
+    flat["W_mem"] *= 128.0; flat["W_att"] *= 8.0; flat["W_fc"] *= 0.125
     flat["W_mem"][:, 5] *= 100.0
     flat["W_mem"][:, 9] *= 1e-5
     flat["W_att"][128:, 17] *= 12.5
@@ -288,7 +293,7 @@ def test_split_operands_adversarial_attention(rv, oracle):
                    bc.get_tensor("parent_ids").reshape(S, B, W), bc.get_tensor("chunk_steps").astype(int))
     taps = {}
     ot, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
-    assert np.abs(taps["keys"]).max() > 1000.0 and taps["step_alignments"][:, 0].max() == 1.0
+    assert np.abs(taps["keys"]).max() > 1000.0 and taps["step_alignments"][:, 0].max() == 1.0 and taps["step_alignments"].max(-1).mean() > 0.6
     assert np.abs(bc.get_tensor("enc_output").reshape(B, Tr + Te, 256) - taps["enc_output"]).max() < TOL
     end = bc.cfg.oracle_cfg()["end_token"]
     for mx in (1, 0):

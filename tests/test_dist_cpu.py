@@ -48,6 +48,15 @@ class _OracleEngine:
         return bases, probs, lens
 
 
+    # asynchronous calls, emulated in order (the host logic of dist.sharded_beam_search_stream / Basecaller.beam_search_stream)
+    async_depth = 2
+
+    def submit_beam_search(self, input_data, beam_width, max_output_len):
+        return {"result": self.beam_search_prediction(input_data, beam_width, max_output_len)}
+
+    def collect(self, call):
+        return call.pop("result")
+
     def beam_search_calls(self, input_data, beam_width, max_output_len):
         bases, probs, lens = self.beam_search_call_arrays(input_data, beam_width, max_output_len)
         return ([bytes(bases[i, :n]).decode() for i, n in enumerate(lens)], [probs[i, :n] for i, n in enumerate(lens)])
@@ -137,3 +146,45 @@ def test_sharded_equals_single(rv, n, eos_bias):
     assert tok.shape == rtok.shape
     assert (tok == rtok).all()
     assert np.array_equal(sc, rsc)
+
+
+def _stream_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravvent_basecaller_amd as rv
+    cfg = rv.RvConfig()
+    flat = rv.weights.init_weights(cfg, seed=4)
+    flat["b_fc"][1] = 1.5
+    eng = _OracleEngine(cfg, rv.weights.pack(cfg, flat))
+    slabs = [rv.synthetic.make_slab(n, 24, 6, seed=20 + n)[:2] for n in (5, 1, 8, 4, 7)]      # n = 1: rank 1's shard is empty
+    outs = list(rv.dist.sharded_beam_search_stream(eng, slabs, beam_width=3, max_output_len=9, slab=3))   # (8 chunks: shard of 4 > slab 3)
+    if rank == 0:
+        q.put([(t.numpy(), s.numpy()) for t, s in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stream_equals_single(rv):
+    """dist.sharded_beam_search_stream: slab k + 1's shard is submitted before slab k is collected and gathered; one collective per
+    slab, results in slab order, identical to the single-process decode -- with an empty shard and a shard larger than the slab limit."""
+    from oracle import cpu_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 555) % 2000
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = rv.RvConfig()
+    flat = rv.weights.init_weights(cfg, seed=4)
+    flat["b_fc"][1] = 1.5
+    blob = rv.weights.pack(cfg, flat)
+    assert len(outs) == 5
+    for (tok, sc), n in zip(outs, (5, 1, 8, 4, 7)):
+        raw, ev, _ = rv.synthetic.make_slab(n, 24, 6, seed=20 + n)
+        rtok, rsc = cpu_port.run(cfg.oracle_cfg(), 2, 7, blob, raw, ev, 3, 9)
+        assert tok.shape == rtok.shape and (tok == rtok).all() and np.array_equal(sc, rsc), n
