@@ -184,6 +184,8 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
   const int dbg = dbg_arg;
   __shared__ __align__(16) char Bs[3][32768];
   __shared__ __align__(16) float css[4 * RV_E];            // column factors of up to 4 column blocks
+  __shared__ __align__(16) float bss[4 * RV_E];            // ... and their biases (zeros without one): the epilogue must not load from global
+                                                           // memory -- 32 dependent L2 round trips per pair cost more than the pair's MFMAs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // a workgroup's stream: its row tiles (blockIdx.x, + gridDim.x, ...), and for each of them the ncb column blocks in turn
   const int nloc = ncb * ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);     // (tile, column block) pairs (>= 1)
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
     // the youngest batch.
     const int p = tid - 256;                               // 0..127
     const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)ncb * 8 * 32768);
-    for (int i = p; i < ncb * RV_E; i += 128) css[i] = cs[i];
+    for (int i = p; i < ncb * RV_E; i += 128) { css[i] = cs[i]; bss[i] = bias ? bias[i] : 0.f; }
     const int nslab = 8 * ncb;
     auto dma = [&](int slab) {
       const char* src = reinterpret_cast<const char*>(img) + (size_t)(slab % nslab) * 32768 + p * 16;
@@ -252,18 +254,27 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
         if (ks & 1) RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a1); else RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a0);
       }
       const char* bs = Bs[(8 * n + ks) % 3] + lane * 16;
+      // B fragments of column tile nt + 1 are read from LDS while the six MFMAs of tile nt run (two fragment pairs live): without the
+      // explicit pipeline every tile waits a full LDS round trip before its MFMAs, and with no fences the scheduler hoists all 32
+      // reads of the k-step and spills
+      h8 bh = *reinterpret_cast<const h8*>(bs), bl = *reinterpret_cast<const h8*>(bs + 1024);
 #pragma unroll
       for (int nt = 0; nt < 16; ++nt) {
-        const h8 bh = *reinterpret_cast<const h8*>(bs + (2 * nt) * 1024), bl = *reinterpret_cast<const h8*>(bs + (2 * nt + 1) * 1024);
-        if (dbg & 4) continue;
+        h8 bhn = bh, bln = bl;
+        if (nt + 1 < 16) { bhn = *reinterpret_cast<const h8*>(bs + (2 * nt + 2) * 1024); bln = *reinterpret_cast<const h8*>(bs + (2 * nt + 3) * 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          // operands swapped: the tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of this row tile), so a
-          // lane ends up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][nt], 0, 0, 0);
+          for (int m = 0; m < 2; ++m) {
+            // operands swapped: the tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of this row tile), so a
+            // lane ends up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][nt], 0, 0, 0);
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][nt], 0, 0, 0);
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][nt], 0, 0, 0);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        bh = bhn; bl = bln;
       }
       RV_LDS_BARRIER();
     }
@@ -275,9 +286,9 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
         for (int nt = 0; nt < 16; ++nt) {
           const int col = cb * RV_E + 16 * nt + 4 * q;
           const float4 f = *reinterpret_cast<const float4*>(&css[col]);
-          float4 o = make_float4(acc[m][nt][0] * f.x, acc[m][nt][1] * f.y, acc[m][nt][2] * f.z, acc[m][nt][3] * f.w);
-          if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + col); o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
-          *reinterpret_cast<float4*>(&C[(size_t)row * ldc + col]) = o;
+          const float4 bb = *reinterpret_cast<const float4*>(&bss[col]);
+          *reinterpret_cast<float4*>(&C[(size_t)row * ldc + col]) =
+              make_float4(fmaf(acc[m][nt][0], f.x, bb.x), fmaf(acc[m][nt][1], f.y, bb.y), fmaf(acc[m][nt][2], f.z, bb.z), fmaf(acc[m][nt][3], f.w, bb.w));
         }
       }
     }

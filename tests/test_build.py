@@ -24,13 +24,14 @@ LIMITS = {
     r"k_gemm_mem_split3": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
     r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
     r"k_lstm_rec_twILi2ELi1EE": 0, r"k_lstm_rec_twILi2ELi5EE": 0,   # C3 layer 0 (tail-wave variant)
+    r"k_lstm_rec_mxILi[01]EE": 0,                # matrix-pipe recurrence: U^T resident as A fragments (128 VGPRs)
 }
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_hot_kernels_do_not_spill(tmp_path):
     found = {}
-    for src, extra in (("decode.hip", []), ("lstm_rec.hip", ["-fno-slp-vectorize"]), ("gemm_f32.hip", [])):
+    for src, extra in (("decode.hip", []), ("lstm_rec.hip", ["-fno-slp-vectorize"]), ("lstm_mx.hip", []), ("gemm_f32.hip", [])):
         out = tmp_path / (src + ".s")
         subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra,
                         os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
