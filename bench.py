@@ -41,22 +41,24 @@ PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROA
 PEAK_NOTE = ("fp32 matrix / vector peak, the arithmetic type the path computes in; its input projections and its Luong scores / context "
              "take each fp32 product as three exact f16 part products on v_mfma_f32_16x16x32_f16 (2.5 PFLOP/s pipe), the recurrences, "
              "the decoder cell and the softmax run packed fp32 FMAs: FLOPs counted are the algorithm's fp32 FLOPs, not MFMA operations")
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md): what the split-operand GEMMs issue their part products on
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 DEC_FLOPS = lambda Tm: 369408 + 768 * Tm     # per beam row per decode step
 
 
-def algorithmic_flops(kernel, B, T_r, T_e, W, S, chunk_steps=None):
+def algorithmic_flops(kernel, B, T_r, T_e, W, S, chunk_steps=None, wide=False):
     """Algorithmic FLOPs of ONE launch of `kernel` (2 per MAC, pointwise ignored).  The decode is credited
     B*W*S row-steps like the reference's slab-wide loop; `chunk_steps` (steps every chunk really ran in the persistent
     decode, which leaves a chunk once its beams are finished) gives the executed count instead."""
     Tm = T_r + T_e
     rec = 2 * 128 * 512 * 2            # recurrent product, both directions, per chunk-step
     rows = B * S if chunk_steps is None else int(sum(chunk_steps))
+    proj = 0 if wide else 256 * 1024 * 2    # matrix-pipe recurrence: the layer >= 1 input projection is its own launch (gemm_inproj_*)
     return {
         "lstm_rec_raw_l0": B * T_r * (rec + 2 * 1 * 512 * 2),
         "lstm_rec_event_l0": B * T_e * (rec + 2 * 5 * 512 * 2),
-        "lstm_rec_raw_l1p": B * T_r * (rec + 256 * 1024 * 2),      # recurrence + the fused input projection (MFMA waves)
-        "lstm_rec_event_l1p": B * T_e * (rec + 256 * 1024 * 2),
+        "lstm_rec_raw_l1p": B * T_r * (rec + proj),      # recurrence (+ the fused input projection of the packed-FMA form)
+        "lstm_rec_event_l1p": B * T_e * (rec + proj),
         "gemm_inproj_raw": B * T_r * 256 * 1024 * 2,     # both directions per launch
         "gemm_inproj_event": B * T_e * 256 * 1024 * 2,
         "gemm_keys": B * Tm * 256 * 128 * 2,
@@ -413,9 +415,18 @@ def main():
                 r = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                      "bytes_per_launch": by, "traffic": None}
+            elif name.startswith("gemm_") and not args.per_step_decode:
+                # split-operand GEMMs: every fp32 product is three exact f16 part products on v_mfma_f32_16x16x32_f16 -- priced as the
+                # MFMA operations they issue (3 x the algorithmic FLOPs) against the dense f16 MFMA peak
+                fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, wide=wide_used)
+                achieved = 3 * fl / (avg_ms * 1e-3) / 1e12
+                r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                     "flops_per_launch": fl, "mfma_ops_per_launch": 3 * fl, "traffic": None,
+                     "peak_note": "dense f16 MFMA peak; achieved = 3 x algorithmic FLOPs (three exact f16 part products per fp32 product) / launch time"}
             else:
-                fl_ref = algorithmic_flops(name, Bk, T_r, T_e, W, S)
-                fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, chunk_steps) if fl_ref else None
+                fl_ref = algorithmic_flops(name, Bk, T_r, T_e, W, S, wide=wide_used)
+                fl = algorithmic_flops(name, Bk, T_r, T_e, W, S, chunk_steps, wide=wide_used) if fl_ref else None
                 achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
                 r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3) if achieved else None,
                      "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -446,7 +457,7 @@ def main():
         else:
             roof = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass, the launch alone on the chip")
         roof["share_of_cu_time"] = round(cu_ms[name] / sum(cu_ms.values()), 3)
-        if roof["bound"] == "mfma":
+        if roof["bound"] == "mfma" and "peak_note" not in roof:
             roof["peak_note"] = PEAK_NOTE
         roof_iso = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass of synchronous calls, the launch alone on the chip")
         top2 = [roof_of(k, per_slab[k], 10, "hipEvents, untimed pass, the launch alone on the chip") for k in order[1:3]
@@ -493,7 +504,8 @@ def main():
             "kernel_ms_per_launch_alone": {k: round(v, 4) for k, v in sorted(per_slab.items())},
             "kernel_cu_ms_per_slab": {k: round(v, 4) for k, v in sorted(cu_ms.items())},
             "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
-            "step_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
+            # (streamed steps complete in bursts: these are intervals between step COMPLETIONS, not step latencies)
+            "step_completion_interval_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
         }
         if sync_ms is not None:
             out["synchronous"] = {"ms_per_step": round(sync_ms, 4), "chunks_per_s": round(Bk / sync_ms * 1e3, 1),

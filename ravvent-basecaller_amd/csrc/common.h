@@ -78,6 +78,7 @@ void launch_gemm_mem_split(const float* A, int M, const uint16_t* img, float* C,
 // row tile one after the other, so A comes from HBM once.  The input projection of encoder layers >= 1 for the matrix-pipe
 // recurrence: ncb = 4 (two directions x 512 gate columns), ldc = 1024, bias = [b_fwd | b_bwd].
 #define RV_WX16_SLOT ((size_t)2 * RV_E * 2 * RV_G + 2 * 2 * RV_G)
+hipError_t configure_gemm_kernels();   // dynamic-LDS opt-in of the weight-stationary split GEMM
 void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int ncb, const float* bias, float* C, int ldc, hipStream_t s);
 
 // ---------------------------------------------------------------- small encoder-side kernels

@@ -297,6 +297,114 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
 #undef RV_A_LOAD
 }
 
+// ------------------------------------------------------------------------------------------------
+// (4) WEIGHT-STATIONARY form (round 3; what launch_gemm_split_blocks runs).  Probes of form (3) on the encoder input projection
+// (C3: M = 76,800, N = 1,024; tools/gemm_probe.sh) showed its parts ADD -- slab staging + barriers 0.054 ms, MFMAs + 0.098, C stores
+// + 0.05: one workgroup per CU whose six waves meet at a barrier every k-step leaves nothing to overlap with.  Here a workgroup
+// keeps ONE half column block (128 columns x K = 256, two f16 parts: 128 KB) in LDS for its whole life and its eight waves
+// (two per SIMD) run free: a wave takes 32-row tiles of its workgroup's row group, loads its own A rows straight into registers
+// (four stream positions in flight: a 4-slot ring, 8 k-steps per tile, so slot = k-step % 4 at compile time, across tile
+// boundaries too), splits them, multiplies against the resident fragments (64 accumulator registers: 32 rows x 128 columns) and
+// stores -- no barrier after the weight load, so one wave's loads, conversions and stores run under the other wave's MFMAs.
+// The vector-memory counter retires in order and counts stores: with four positions in flight the loads a new tile needs in its
+// first four k-steps were issued BEFORE the previous tile's stores, which therefore drain in the background.
+// Workgroup id -> (row group, column half): the 2 ncb workgroups that share a row group have the same id % 8, i.e. sit on one
+// XCD and run at the same time, so the row group's A rows come from HBM once and from that XCD's L2 otherwise.
+__global__ __launch_bounds__(512) void k_gemm_ws(const float* __restrict__ A, int M, const uint16_t* __restrict__ img, int ncb,
+                                                 const float* __restrict__ bias, float* __restrict__ C, int ldc, int nrg) {
+  extern __shared__ __align__(16) char wsm[];
+  char* Bl = wsm;                                                    // [8 k-steps][8 column tiles][2 parts][64 lanes][8 f16] = 128 KB
+  float* css = reinterpret_cast<float*>(wsm + 131072);               // [128] column factors, [128] biases
+  float* bss = css + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int nch = 2 * ncb;                                           // half column blocks
+  const int id = blockIdx.x;
+  const int rg = (id & 7) + 8 * (id / (8 * nch)), ch = (id >> 3) % nch;
+  const int cb = ch >> 1, hb = ch & 1, col0 = cb * RV_E + hb * 128;
+  {
+    const char* src = reinterpret_cast<const char*>(img) + (size_t)cb * 8 * 32768 + hb * 16384;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<float4*>(Bl + ks * 16384 + i * 8192 + tid * 16) = *reinterpret_cast<const float4*>(src + (size_t)ks * 32768 + i * 8192 + tid * 16);
+    const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)ncb * 8 * 32768);
+    if (tid < 128) { css[tid] = cs[col0 + tid]; bss[tid] = bias ? bias[col0 + tid] : 0.f; }
+  }
+  __syncthreads();
+  const int ntile = (M + 31) / 32;
+  // this wave's tiles: t_j = rg + nrg * (wave + 8 j)
+  const int tstride = 8 * nrg;
+  int t = rg + nrg * wave;
+  if (t >= ntile) return;
+  float4 ar[4][2][2];                                                // [slot][row tile][half]
+#define RV_WS_LOAD(tile_, ks_, slot_) do { \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) { \
+      const float* ap_ = A + (size_t)min((tile_) * 32 + 16 * m_ + l16, M - 1) * RV_E + 8 * q + 32 * (ks_); \
+      ar[slot_][m_][0] = *reinterpret_cast<const float4*>(ap_); ar[slot_][m_][1] = *reinterpret_cast<const float4*>(ap_ + 4); } } while (0)
+  RV_WS_LOAD(t, 0, 0); RV_WS_LOAD(t, 1, 1); RV_WS_LOAD(t, 2, 2); RV_WS_LOAD(t, 3, 3);
+  for (; t < ntile; t += tstride) {
+    const int tn = t + tstride < ntile ? t + tstride : t;            // (the last tile re-reads four of its own k-steps: L2 hits, dropped)
+    f4v acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      h8 ah[2], al[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float4 x0 = ar[ks & 3][m][0], x1 = ar[ks & 3][m][1];
+        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sv = v[j] * 16384.f;
+          ah[m][j] = (_Float16)sv;
+          al[m][j] = (_Float16)(sv - (float)ah[m][j]);
+        }
+      }
+      if (ks < 4) RV_WS_LOAD(t, ks + 4, ks & 3); else RV_WS_LOAD(tn, ks - 4, ks & 3);     // stream position + 4, into the slot just consumed
+      const char* bs = Bl + ks * 16384 + lane * 16;
+      h8 bh = *reinterpret_cast<const h8*>(bs), bl = *reinterpret_cast<const h8*>(bs + 1024);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        h8 bhn = bh, bln = bl;
+        if (nt + 1 < 8) { bhn = *reinterpret_cast<const h8*>(bs + (2 * nt + 2) * 1024); bln = *reinterpret_cast<const h8*>(bs + (2 * nt + 3) * 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // operands swapped: the tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of this row tile), so a
+          // lane ends up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bh = bhn; bl = bln;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int row = t * 32 + 16 * m + l16;                        // C/D map of the transposed tile: column = lane % 16 = row of C,
+      if (row < M) {                                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          const float4 f = *reinterpret_cast<const float4*>(&css[16 * nt + 4 * q]), bb = *reinterpret_cast<const float4*>(&bss[16 * nt + 4 * q]);
+          *reinterpret_cast<float4*>(&C[(size_t)row * ldc + col0 + 16 * nt + 4 * q]) =
+              make_float4(fmaf(acc[m][nt][0], f.x, bb.x), fmaf(acc[m][nt][1], f.y, bb.y), fmaf(acc[m][nt][2], f.z, bb.z), fmaf(acc[m][nt][3], f.w, bb.w));
+        }
+      }
+    }
+  }
+#undef RV_WS_LOAD
+}
+constexpr int GEMM_WS_LDS = 131072 + 1024;
+
+hipError_t configure_gemm_kernels() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_WS_LDS);
+}
+
 void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int ncb, const float* bias, float* C, int ldc, hipStream_t s) {
   const int nt128 = (M + 127) / 128;
   int dbg = 0;
@@ -304,6 +412,18 @@ void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int nc
   static const int dbg_env = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
   dbg = dbg_env;
 #endif
+  static const bool old_form = getenv("RV_GEMM_FORM3") != nullptr;      // A/B timing of the slab-streaming form (same results)
+  // ncb == 1 (the attention-memory projection, N = 256) stays on form (3): with two column halves a workgroup would load its 128 KB of
+  // weights for some twenty 32-row tiles, and the load shows (0.056 vs 0.052 ms at C3)
+  if (!old_form && !dbg && ncb > 1) {
+    // row groups: 8 k with 8 k x 2 ncb ~ 256 workgroups, but no more groups than there are 8-tile bundles of work
+    const int nch = 2 * ncb, ntile = (M + 31) / 32;
+    int k = 256 / (8 * nch);
+    while (k > 1 && 8 * (k - 1) * 8 >= ntile) --k;                // keep every wave of every workgroup busy with at least one tile where possible
+    const int nrg = 8 * k;
+    hipLaunchKernelGGL(k_gemm_ws, dim3(nrg * nch), dim3(512), GEMM_WS_LDS, s, A, M, img, ncb, bias, C, ldc, nrg);
+    return;
+  }
   const dim3 grid(nt128 < 256 ? nt128 : 256), block(384);
   if (ncb == 1) hipLaunchKernelGGL(k_gemm_mem_split3<1>, grid, block, 0, s, A, M, img, C, nt128, dbg, ldc, bias);
   else if (ncb == 4) hipLaunchKernelGGL(k_gemm_mem_split3<4>, grid, block, 0, s, A, M, img, C, nt128, dbg, ldc, bias);

@@ -58,29 +58,49 @@ inline double affine(int length, double open, double extend) {   // calc_affine_
 }
 
 // The DP swept by anti-diagonals (cells (r, d - r)): no cell of a diagonal depends on another one of it, so the loop over r
-// vectorises (doubles; the same operations in the same order per cell as the row-major loop of the reference, hence
-// bit-identical).  Work arrays are indexed by row: h1 / h2 = scores of diagonals d-1 / d-2, e1 = the column state left by
-// the cell above (diagonal d-1), f = the row state carried along each row, ga / ea = gap-open / gap-extend cost of a gap in
-// A for that row (0 in the last row: free end gaps).  mtab[a*4+b] = match score; ia / ib = letter indices (identity
-// scoring uses a 2-entry table through ia == ib).
+// vectorises -- doubles, the same operations in the same order per cell as the row-major loop of the reference, hence
+// bit-identical.  Everything is indexed by ROW r = 0 .. nl-1 (nl = rows rounded up to a multiple of 8: a fixed-width loop with no
+// remainder; rows without a cell on the diagonal are computed and masked): h1 / h2 = scores of diagonals d-1 / d-2, e1 = the column
+// state left by the cell above (diagonal d-1), f = the row state carried along each row, ga / ea = gap-open / gap-extend cost of a
+// gap in A for that row (0 in the last row: free end gaps), ia = the row's letter code, ibr = B's letter codes REVERSED, so that the
+// letters a diagonal meets are contiguous in r.  Scores and trace codes are stored diagonal-major, [d][r] -- what the sweep writes
+// with plain vector stores -- and the traceback reads cell (r, c) at [(r + c) * nl + r].
+// (Round 3: the row-major stores, per-diagonal trip counts and the gather of the first form cost 9 of the 13 us a chunk pair took
+//  on a 2.1 GHz Xeon -- more than the GPU needs for the chunk.)
 __attribute__((target_clones("avx512f", "avx2", "default")))
-static double fill_diagonals(int lenA, int lenB, double first_gap, double extend, double open2, const int* __restrict__ ia,
-                             const int* __restrict__ ib, const double* __restrict__ mtab, int mstride, double* __restrict__ work,
-                             int* __restrict__ tn, double* __restrict__ score, int* __restrict__ trace) {
-  const int n = lenA + 2, W = lenB + 1;
-  double* h1 = work, *h2 = work + n, *hn = work + 2 * n, *e1 = work + 3 * n, *en = work + 4 * n;
-  double* f = work + 5 * n, *ga = work + 6 * n, *ea = work + 7 * n, *mm = work + 8 * n;
+static double fill_diagonals(int lenA, int lenB, int nl, double first_gap, double extend, double open2, const int* __restrict__ ia,
+                             const int* __restrict__ ibr, const double* __restrict__ mtab, int mstride, double* __restrict__ work,
+                             double* __restrict__ score, int* __restrict__ trace) {
+  // work: 8 arrays of nl + 8 doubles; element r of an array lives at [8 + r], so that [r - 1] of row 0 is addressable
+  const int ws = nl + 8;
+  double* hbuf[3] = {work + 8, work + 8 + ws, work + 8 + 2 * ws};       // scores of three consecutive diagonals, rotating
+  double* ebuf[2] = {work + 8 + 3 * ws, work + 8 + 4 * ws};             // column states of two
+  double* __restrict__ f = work + 8 + 5 * ws;
+  const double* __restrict__ ga = f + ws;
+  const double* __restrict__ ea = ga + ws;
   double local_max = 0;
   for (int d = 2; d <= lenA + lenB; ++d) {
     const int r_lo = d - lenB > 1 ? d - lenB : 1, r_hi = lenA < d - 1 ? lenA : d - 1, r_lastcol = d - lenB;
+    // (block-scope restrict: the five arrays of a diagonal are distinct -- without it the loop below does not vectorise)
+    const double* __restrict__ h1 = hbuf[(d + 2) % 3];     // diagonal d-1
+    const double* __restrict__ h2 = hbuf[(d + 1) % 3];     // diagonal d-2
+    double* __restrict__ hn = hbuf[d % 3];
+    double* __restrict__ e1 = ebuf[(d + 1) & 1];
+    double* __restrict__ en = ebuf[d & 1];
     {   // column state of column d-1 before row 1 (used by cell (1, d-1)): calc_affine_penalty(d-1, 2*open, extend)
       double p = open2 + extend * (d - 1); p -= extend; e1[0] = p;
     }
+    const int* __restrict__ ibd = ibr + (lenB - d);        // ibd[r] = code of B[d - r - 1]
+    double* __restrict__ sd = score + (size_t)d * nl;
+    int* __restrict__ td = trace + (size_t)d * nl;
+    // rows r_lo .. r_hi hold this diagonal's cells; the loop covers the enclosing 8-aligned window plus row r_hi + 1 (the border cell
+    // (r, 0) of diagonal d = r, read as 0 by the next diagonals); rows outside it are never read again by a valid cell
+    const int w_lo = r_lo & ~7, w_end = (r_hi + 9) & ~7, w_hi = w_end < nl ? w_end : nl;
 #pragma clang loop vectorize(enable) interleave(disable)
-    for (int r = r_lo; r <= r_hi; ++r) mm[r] = mtab[ia[r - 1] * mstride + ib[d - r - 1]];
-#pragma clang loop vectorize(enable) interleave(disable)
-    for (int r = r_lo; r <= r_hi; ++r) {
-      const double nogap = h2[r - 1] + mm[r];
+    for (int r = w_lo; r < w_hi; ++r) {
+      const bool valid = r >= r_lo && r <= r_hi;
+      const double mm = mtab[ia[r] * mstride + ibd[r]];
+      const double nogap = h2[r - 1] + mm;
       const double row_open = h1[r] + ga[r], row_extend = f[r] + ea[r];
       const double rs = row_open > row_extend ? row_open : row_extend;
       const bool lastcol = r == r_lastcol;               // column lenB: free end gaps in B
@@ -88,7 +108,8 @@ static double fill_diagonals(int lenA, int lenB, double first_gap, double extend
       const double cs = col_open > col_extend ? col_open : col_extend;
       double b = cs > rs ? cs : rs;
       b = nogap > b ? nogap : b;
-      f[r] = rs; en[r] = cs; hn[r] = b < 0 ? 0.0 : b;
+      const double hv = valid ? (b < 0 ? 0.0 : b) : 0.0;
+      f[r] = valid ? rs : f[r]; en[r] = cs; hn[r] = hv;
       // pairwise2.rint(x) = int(x * 1000 + 0.5); rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y))
       const int ro = (int)(row_open * 1000 + 0.5), re = (int)(row_extend * 1000 + 0.5);
       const int co = (int)(col_open * 1000 + 0.5), ce = (int)(col_extend * 1000 + 0.5), ng = (int)(nogap * 1000 + 0.5);
@@ -97,17 +118,11 @@ static double fill_diagonals(int lenA, int lenB, double first_gap, double extend
       int t = ng == br ? 2 : 0;
       t += rr == br ? (ro == rr ? 1 : 0) + (re == rr ? 8 : 0) : 0;
       t += cr == br ? (co == cr ? 4 : 0) + (ce == cr ? 16 : 0) : 0;
-      tn[r] = t;
+      sd[r] = hv; td[r] = valid ? t : -1;
     }
-    for (int r = r_lo; r <= r_hi; ++r) {                  // (best score = max over the clipped cells: it starts at 0 in the reference too)
-      score[(size_t)r * W + d - r] = hn[r]; trace[(size_t)r * W + d - r] = tn[r];
-      local_max = local_max > hn[r] ? local_max : hn[r];
-    }
-    // rotate: d-1 -> d-2, d -> d-1; the border cells (0, d) and (d, 0) of the new diagonal d are zero
-    hn[0] = 0.0; if (d <= lenA) hn[d] = 0.0;
-    if (r_lo > 1) hn[r_lo - 1] = 0.0;                     // (row r_lo-1 has no cell on this diagonal any more: beyond column lenB)
-    double* t = h2; h2 = h1; h1 = hn; hn = t;
-    double* te = e1; e1 = en; en = te;
+    // best score = max over the clipped cells (it starts at 0 in the reference too); kept out of the loop above: without fast-math
+    // the compare-select maximum is not a reduction the vectoriser accepts.  Rows without a cell on diagonal d hold 0, the border value.
+    for (int r = r_lo; r <= r_hi; ++r) local_max = local_max > sd[r] ? local_max : sd[r];
   }
   return local_max;
 }
@@ -128,8 +143,9 @@ struct Aligner {
   double best = 0;
   int W = 0;
 
-  double& S(int r, int c) { return score[(size_t)r * W + c]; }
-  int& T(int r, int c) { return trace[(size_t)r * W + c]; }
+  int NL = 8;                    // row stride of the diagonal-major matrices
+  double& S(int r, int c) { return score[(size_t)(r + c) * NL + r]; }
+  int& T(int r, int c) { return trace[(size_t)(r + c) * NL + r]; }
 
   double match_fn(char a, char b) const {
     if (!sc.matrix) return a == b ? sc.match : sc.mismatch;
@@ -138,53 +154,61 @@ struct Aligner {
 
   void fill() {                  // _make_score_matrix_fast: local, penalize_end_gaps (False, False); swept by anti-diagonals
     W = lenB + 1;
-    score.assign((size_t)(lenA + 1) * W, 0.0);
-    trace.assign((size_t)(lenA + 1) * W, -1);
+    NL = (lenA + 1 + 7) & ~7;
+    const int nd = lenA + lenB + 1;
+    score.assign((size_t)nd * NL, 0.0);                     // borders and cells off the matrix: score 0, trace None
+    trace.assign((size_t)nd * NL, -1);
     const double open = sc.open, extend = sc.extend;
     const double first_gap = affine(1, open, extend);
-    const int n = lenA + 2;
-    dbuf.assign((size_t)9 * n, 0.0);
-    double* f = &dbuf[5 * n], *ga = &dbuf[6 * n], *ea = &dbuf[7 * n];
-    tbuf.assign(n, 0);
-    ia.resize(lenA); ib.resize(lenB);
+    const int ws = NL + 8;
+    dbuf.assign((size_t)8 * ws + 8, 0.0);
+    double* f = &dbuf[8 + 5 * ws], *ga = f + ws, *ea = ga + ws;
+    ia.assign(NL, 0);
+    ib.assign((size_t)lenB + 2 * NL + 2 * lenA + 16, 0);    // reversed letters of B with room for every row of every diagonal
+    int* ibr = ib.data() + NL + lenA + 8;                   // index range used: 1 - lenA .. lenB - 2 + NL
     double mtab[16];
+    int code[256]; for (int i = 0; i < 256; ++i) code[i] = -1;
+    int ncode = 0;
+    const double* tab = mtab; int stride = 4;
     if (sc.matrix) {
       for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) mtab[i * 4 + k] = sc.m[i][k];
-      for (int i = 0; i < lenA; ++i) ia[i] = base_index(A[i]);
-      for (int i = 0; i < lenB; ++i) ib[i] = base_index(B[i]);
-    } else {     // identity scoring on arbitrary letters: index = (a != b) through a per-pair comparison below
-      for (int i = 0; i < lenA; ++i) ia[i] = (unsigned char)A[i];
-      for (int i = 0; i < lenB; ++i) ib[i] = (unsigned char)B[i];
+      for (int i = 0; i < lenA; ++i) ia[i + 1] = base_index(A[i]);
+      for (int i = 0; i < lenB; ++i) ibr[lenB - 1 - i] = base_index(B[i]);
+    } else {
+      // identity scoring on arbitrary letters: codes of first occurrence (at most 2 * overlap distinct letters) index a table with
+      // `match` on its diagonal
+      for (int i = 0; i < lenA; ++i) { const int ch = (unsigned char)A[i]; if (code[ch] < 0) code[ch] = ncode++; ia[i + 1] = code[ch]; }
+      for (int i = 0; i < lenB; ++i) { const int ch = (unsigned char)B[i]; if (code[ch] < 0) code[ch] = ncode++; ibr[lenB - 1 - i] = code[ch]; }
+      itab.assign((size_t)ncode * ncode, sc.mismatch);
+      for (int i = 0; i < ncode; ++i) itab[(size_t)i * ncode + i] = sc.match;
+      tab = itab.data(); stride = ncode;
     }
     for (int r = 1; r <= lenA; ++r) {
       f[r] = affine(r, 2 * open, extend);                 // row state before column 1
       ga[r] = r == lenA ? 0.0 : first_gap; ea[r] = r == lenA ? 0.0 : extend;
     }
-    if (sc.matrix) {
-      best = fill_diagonals(lenA, lenB, first_gap, extend, 2 * open, ia.data(), ib.data(), mtab, 4, dbuf.data(), tbuf.data(), score.data(), trace.data());
-    } else {
-      // identity: a 256 x 256 table would defeat the purpose; map letters to 0..3 when both strings are ACGT, else fall back to codes
-      // of first occurrence (at most 50 distinct letters in two 25-letter strings -> table of 64 x 64)
-      int code[256]; for (int i = 0; i < 256; ++i) code[i] = -1;
-      int ncode = 0;
-      for (int i = 0; i < lenA; ++i) { if (code[ia[i]] < 0) code[ia[i]] = ncode++; }
-      for (int i = 0; i < lenB; ++i) { if (code[ib[i]] < 0) code[ib[i]] = ncode++; }
-      for (int i = 0; i < lenA; ++i) ia[i] = code[ia[i]];
-      for (int i = 0; i < lenB; ++i) ib[i] = code[ib[i]];
-      itab.assign((size_t)ncode * ncode, sc.mismatch);
-      for (int i = 0; i < ncode; ++i) itab[(size_t)i * ncode + i] = sc.match;
-      best = fill_diagonals(lenA, lenB, first_gap, extend, 2 * open, ia.data(), ib.data(), itab.data(), ncode, dbuf.data(), tbuf.data(), score.data(), trace.data());
-    }
+    best = fill_diagonals(lenA, lenB, NL, first_gap, extend, 2 * open, ia.data(), ibr, tab, stride, dbuf.data(), score.data(), trace.data());
   }
 
   void find_start(std::vector<Start>& st) {
     st.clear();
-    const size_t n = (size_t)(lenA + 1) * W;
-    for (size_t i = 0; i < n; ++i) {
-      const double s = score[i];
-      const double d = s > best ? s - best : best - s;
-      if (d * 1000 + 0.5 < 1.0) st.push_back({s, (int)(i / W), (int)(i % W)});   // rint(abs(s - best)) <= rint(0)
+    const double lim = best - 0.001;                       // cheap filter (twice the bucket width); candidates take the exact test below
+    auto exact = [&](double s) { const double d = s > best ? s - best : best - s; return d * 1000 + 0.5 < 1.0; };   // rint(abs(s - best)) <= rint(0)
+    if (lim > 0.0) {
+      // the usual case: a positive best score.  Cells off the matrix hold 0 < lim, so a flat scan of the diagonal-major storage finds
+      // the (few) candidates; they are then put into the row-major order in which the reference scans its matrix
+      const size_t n = (size_t)(lenA + lenB + 1) * NL;
+      const double* sp = score.data();
+      for (size_t i = 0; i < n; ++i)
+        if (sp[i] >= lim && exact(sp[i])) { const int r = (int)(i % NL), d = (int)(i / NL); st.push_back({sp[i], r, d - r}); }
+      std::sort(st.begin(), st.end(), [](const Start& x, const Start& y) { return x.row != y.row ? x.row < y.row : x.col < y.col; });
+      return;
     }
+    for (int r = 0; r <= lenA; ++r)                        // row-major order, as the reference scans its matrix
+      for (int c = 0; c <= lenB; ++c) {
+        const double s = S(r, c);
+        if (s >= lim && exact(s)) st.push_back({s, r, c});
+      }
   }
 
   static void rev_append(std::string& dst, const std::string& src, int from /*inclusive*/, int to /*exclusive, going down*/) {
@@ -312,17 +336,18 @@ struct Aligner {
   void transpose() {             // _reverse_matrices + swapped sequences
     static const int rt[32] = {0, 4, 2, 6, 1, 5, 3, 7, 16, 20, 18, 22, 17, 21, 19, 23,
                                8, 12, 10, 14, 9, 13, 11, 15, 24, 28, 26, 30, 25, 29, 27, 31};
-    std::vector<double> s2((size_t)(lenB + 1) * (lenA + 1));
-    std::vector<int> t2(s2.size());
+    const int nl2 = (lenB + 1 + 7) & ~7;                   // the transposed matrix: rows = columns of this one
+    std::vector<double> s2((size_t)(lenA + lenB + 1) * nl2, 0.0);
+    std::vector<int> t2(s2.size(), -1);
     for (int c = 0; c <= lenB; ++c)
       for (int r = 0; r <= lenA; ++r) {
-        s2[(size_t)c * (lenA + 1) + r] = S(r, c);
+        s2[(size_t)(r + c) * nl2 + c] = S(r, c);
         const int t = T(r, c);
-        t2[(size_t)c * (lenA + 1) + r] = t < 0 ? -1 : rt[t];
+        t2[(size_t)(r + c) * nl2 + c] = t < 0 ? -1 : rt[t];
       }
     score.swap(s2); trace.swap(t2);
     std::swap(A, B); std::swap(lenA, lenB);
-    W = lenB + 1;
+    W = lenB + 1; NL = nl2;
   }
 
   // pairwise2.align.local{ms,ds}(a, b, ...)[0]; false = empty list

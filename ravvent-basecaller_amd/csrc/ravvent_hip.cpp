@@ -819,6 +819,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   HIPTRY(configure_decode_kernels());    // a refused LDS opt-in would otherwise surface as an opaque launch error later
   HIPTRY(configure_rec_kernels());
   HIPTRY(configure_mx_kernels());
+  HIPTRY(configure_gemm_kernels());
   h->n_w = weight_count(c);
   TRY(dalloc(h, &h->d_w, h->n_w));
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
