@@ -308,9 +308,12 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
 // stores -- no barrier after the weight load, so one wave's loads, conversions and stores run under the other wave's MFMAs.
 // The vector-memory counter retires in order and counts stores: with four positions in flight the loads a new tile needs in its
 // first four k-steps were issued BEFORE the previous tile's stores, which therefore drain in the background.
+#ifndef RV_WS_THREADS
+#define RV_WS_THREADS 512
+#endif
 // Workgroup id -> (row group, column half): the 2 ncb workgroups that share a row group have the same id % 8, i.e. sit on one
 // XCD and run at the same time, so the row group's A rows come from HBM once and from that XCD's L2 otherwise.
-__global__ __launch_bounds__(512) void k_gemm_ws(const float* __restrict__ A, int M, const uint16_t* __restrict__ img, int ncb,
+__global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restrict__ A, int M, const uint16_t* __restrict__ img, int ncb,
                                                  const float* __restrict__ bias, float* __restrict__ C, int ldc, int nrg) {
   extern __shared__ __align__(16) char wsm[];
   char* Bl = wsm;                                                    // [8 k-steps][8 column tiles][2 parts][64 lanes][8 f16] = 128 KB
@@ -323,18 +326,16 @@ __global__ __launch_bounds__(512) void k_gemm_ws(const float* __restrict__ A, in
   const int cb = ch >> 1, hb = ch & 1, col0 = cb * RV_E + hb * 128;
   {
     const char* src = reinterpret_cast<const char*>(img) + (size_t)cb * 8 * 32768 + hb * 16384;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<float4*>(Bl + ks * 16384 + i * 8192 + tid * 16) = *reinterpret_cast<const float4*>(src + (size_t)ks * 32768 + i * 8192 + tid * 16);
+    for (int i = tid; i < 8 * 1024; i += RV_WS_THREADS)       // 8 k-steps x 16 KB, 16 bytes per thread and pass
+      *reinterpret_cast<float4*>(Bl + i * 16) = *reinterpret_cast<const float4*>(src + (size_t)(i >> 10) * 32768 + (i & 1023) * 16);
     const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)ncb * 8 * 32768);
     if (tid < 128) { css[tid] = cs[col0 + tid]; bss[tid] = bias ? bias[col0 + tid] : 0.f; }
   }
   __syncthreads();
   const int ntile = (M + 31) / 32;
-  // this wave's tiles: t_j = rg + nrg * (wave + 8 j)
-  const int tstride = 8 * nrg;
+  // this wave's tiles: t_j = rg + nrg * (wave + NW j)
+  constexpr int NW = RV_WS_THREADS / 64;
+  const int tstride = NW * nrg;
   int t = rg + nrg * wave;
   if (t >= ntile) return;
   float4 ar[4][2][2];                                                // [slot][row tile][half]
@@ -364,30 +365,43 @@ __global__ __launch_bounds__(512) void k_gemm_ws(const float* __restrict__ A, in
           al[m][j] = (_Float16)(sv - (float)ah[m][j]);
         }
       }
+#ifndef RV_WS_NOALOAD   // (diagnostic builds: results invalid)
       if (ks < 4) RV_WS_LOAD(t, ks + 4, ks & 3); else RV_WS_LOAD(tn, ks - 4, ks & 3);     // stream position + 4, into the slot just consumed
+#endif
       const char* bs = Bl + ks * 16384 + lane * 16;
-      h8 bh = *reinterpret_cast<const h8*>(bs), bl = *reinterpret_cast<const h8*>(bs + 1024);
+      // Two column tiles at a time: four accumulators (2 row tiles x 2 column tiles) take the three part products in turn, so that
+      // every MFMA has three independent ones between it and the next one on its accumulator (back-to-back MFMAs on ONE accumulator
+      // wait out the full pipeline latency: the first form of this loop, one column tile per group, ran at a third of the MFMA rate).
+      // Operands swapped: a tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of the row tile), so a lane ends
+      // up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones.
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        h8 bhn = bh, bln = bl;
-        if (nt + 1 < 8) { bhn = *reinterpret_cast<const h8*>(bs + (2 * nt + 2) * 1024); bln = *reinterpret_cast<const h8*>(bs + (2 * nt + 3) * 1024); }
+      for (int np = 0; np < 8; np += 2) {
+        const h8 bh0 = *reinterpret_cast<const h8*>(bs + (2 * np) * 1024), bl0 = *reinterpret_cast<const h8*>(bs + (2 * np + 1) * 1024);
+        const h8 bh1 = *reinterpret_cast<const h8*>(bs + (2 * np + 2) * 1024), bl1 = *reinterpret_cast<const h8*>(bs + (2 * np + 3) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          // operands swapped: the tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of this row tile), so a
-          // lane ends up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][nt], 0, 0, 0);
-        }
+        acc[0][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl0, ah[0], acc[0][np], 0, 0, 0);
+        acc[1][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl0, ah[1], acc[1][np], 0, 0, 0);
+        acc[0][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl1, ah[0], acc[0][np + 1], 0, 0, 0);
+        acc[1][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl1, ah[1], acc[1][np + 1], 0, 0, 0);
+        acc[0][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh0, al[0], acc[0][np], 0, 0, 0);
+        acc[1][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh0, al[1], acc[1][np], 0, 0, 0);
+        acc[0][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh1, al[0], acc[0][np + 1], 0, 0, 0);
+        acc[1][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh1, al[1], acc[1][np + 1], 0, 0, 0);
+        acc[0][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh0, ah[0], acc[0][np], 0, 0, 0);
+        acc[1][np] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh0, ah[1], acc[1][np], 0, 0, 0);
+        acc[0][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh1, ah[0], acc[0][np + 1], 0, 0, 0);
+        acc[1][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh1, ah[1], acc[1][np + 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        bh = bhn; bl = bln;
       }
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int row = t * 32 + 16 * m + l16;                        // C/D map of the transposed tile: column = lane % 16 = row of C,
-      if (row < M) {                                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
+#ifdef RV_WS_NOSTORE
+      if (row < M && acc[m][0][0] == 12345.f) {
+#else
+      if (row < M) {
+#endif                                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
           const float4 f = *reinterpret_cast<const float4*>(&css[16 * nt + 4 * q]), bb = *reinterpret_cast<const float4*>(&bss[16 * nt + 4 * q]);
@@ -421,7 +435,7 @@ void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int nc
     int k = 256 / (8 * nch);
     while (k > 1 && 8 * (k - 1) * 8 >= ntile) --k;                // keep every wave of every workgroup busy with at least one tile where possible
     const int nrg = 8 * k;
-    hipLaunchKernelGGL(k_gemm_ws, dim3(nrg * nch), dim3(512), GEMM_WS_LDS, s, A, M, img, ncb, bias, C, ldc, nrg);
+    hipLaunchKernelGGL(k_gemm_ws, dim3(nrg * nch), dim3(RV_WS_THREADS), GEMM_WS_LDS, s, A, M, img, ncb, bias, C, ldc, nrg);
     return;
   }
   const dim3 grid(nt128 < 256 ? nt128 : 256), block(384);

@@ -78,24 +78,28 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     char* dst = hb + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
     *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
   }
-  // pre-projected inputs of the first step
-  float4 xc[4], xn[4];
+  // pre-projected inputs: the loads of step s + 2 are issued in step s (one step, ~1.3 us, is less than an HBM round trip under
+  // load) into a ring of three register sets; the step loop is unrolled by three so that no set is ever COPIED -- a register
+  // move from a load's destination waits for the load, which is what made a "prefetch" into a staging set synchronous
+  float4 xc[4], xn[4], xnn[4];
   const float* xrow = F == 0 ? a.x + ((size_t)bc * T * 2 + dir) * RV_G + u0 : nullptr;    // + t * 1024 + g * 128
   if (F == 0) {
-    const int t0 = dir ? T - 1 : 0;
+    const int t0 = dir ? T - 1 : 0, t1 = dir ? max(T - 2, 0) : min(1, T - 1);
 #pragma unroll
     for (int g = 0; g < 4; ++g) xc[g] = *reinterpret_cast<const float4*>(xrow + (size_t)t0 * (2 * RV_G) + g * RV_U);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xn[g] = *reinterpret_cast<const float4*>(xrow + (size_t)t1 * (2 * RV_G) + g * RV_U);
   }
   __syncthreads();
 
   float hl[4] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  for (int s = 0; s < T; ++s) {
+  auto step = [&](int s, const float4 (&xu)[4], float4 (&xl)[4]) {
     const int t = dir ? T - 1 - s : s;
-    if (F == 0) {                                                // next step's inputs: in flight across the barrier
-      const int tn = dir ? max(t - 1, 0) : min(t + 1, T - 1);
+    if (F == 0) {                                                // the inputs of step s + 2: in flight across two barriers
+      const int tn = dir ? max(t - 2, 0) : min(t + 2, T - 1);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xn[g] = *reinterpret_cast<const float4*>(xrow + (size_t)tn * (2 * RV_G) + g * RV_U);
+      for (int g = 0; g < 4; ++g) xl[g] = *reinterpret_cast<const float4*>(xrow + (size_t)tn * (2 * RV_G) + g * RV_U);
     }
     f4v acc[4];
 #pragma unroll
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     for (int g = 0; g < 4; ++g) {
       const float4 ds = *reinterpret_cast<const float4*>(&dss[g * RV_U + u0]);
       float4 xin;
-      if (F == 0) xin = xc[g];
+      if (F == 0) xin = xu[g];
       else {
         const float xv = xs[n * T + t];
         const float4 wv = *reinterpret_cast<const float4*>(&wxs[g * RV_U + u0]), bv = *reinterpret_cast<const float4*>(&wxs[RV_G + g * RV_U + u0]);
@@ -142,12 +146,13 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     }
     if (live)
       *reinterpret_cast<float4*>(a.out + ((size_t)(b0 + n) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
-    if (F == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xc[g] = xn[g];
-    }
     cur ^= 1;
     RV_MX_BARRIER();
+  };
+  for (int s = 0; s < T; s += 3) {
+    step(s, xc, xnn);
+    if (s + 1 < T) step(s + 1, xn, xc);
+    if (s + 2 < T) step(s + 2, xnn, xn);
   }
   if (live) {
     *reinterpret_cast<float4*>(a.hT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
