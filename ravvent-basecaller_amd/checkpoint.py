@@ -57,11 +57,54 @@ def _crc_table():
 _CRC = _crc_table()
 
 
-def crc32c(data: bytes, crc: int = 0) -> int:
-    crc ^= 0xFFFFFFFF
+def _crc_bytes(data, state: int) -> int:
     for b in data:
-        crc = _CRC[(crc ^ b) & 0xFF] ^ (crc >> 8)
-    return crc ^ 0xFFFFFFFF
+        state = _CRC[(state ^ b) & 0xFF] ^ (state >> 8)
+    return state
+
+
+def _zero_shift_matrix(nbytes: int):
+    """The CRC register after `nbytes` zero bytes is a GF(2)-linear map of the register before them: its 32 columns."""
+    def mul(a, b):                                   # columns of a . b
+        return [_apply(a, col) for col in b]
+    m = [_crc_bytes(b"\x00", 1 << j) for j in range(32)]
+    out, e = [1 << j for j in range(32)], nbytes
+    while e:
+        if e & 1:
+            out = mul(m, out)
+        m = mul(m, m)
+        e >>= 1
+    return out
+
+
+def _apply(mat, x: int) -> int:
+    r, j = 0, 0
+    while x:
+        if x & 1:
+            r ^= mat[j]
+        x >>= 1; j += 1
+    return r
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC32C of `data`.  Large buffers (a checkpoint's kernels are megabytes) are cut into 1024 equal chunks whose registers advance
+    together, one numpy table lookup per byte POSITION, and are then chained through the zero-shift matrix of the chunk length --
+    the byte-at-a-time Python loop of the first version took seconds per checkpoint."""
+    n = len(data)
+    state = crc ^ 0xFFFFFFFF
+    if n < 1 << 14:
+        return _crc_bytes(data, state) ^ 0xFFFFFFFF
+    nchunk = 1024
+    L = n // nchunk
+    a = np.frombuffer(data, np.uint8, count=nchunk * L).reshape(nchunk, L)
+    tab = np.asarray(_CRC, np.uint32)
+    c = np.zeros(nchunk, np.uint32)
+    for i in range(L):
+        c = tab[(c ^ a[:, i]) & 0xFF] ^ (c >> 8)
+    shift = _zero_shift_matrix(L)
+    for k in range(nchunk):                          # register after chunk k = shift(register before it) xor (chunk k from a zero register)
+        state = _apply(shift, state) ^ int(c[k])
+    return _crc_bytes(data[nchunk * L:], state) ^ 0xFFFFFFFF
 
 
 def _mask(crc: int) -> int:
@@ -210,8 +253,10 @@ def write_table(path: str, items: dict, block_entries: int = 8) -> None:
 
 
 # ------------------------------------------------------------------ tensor bundle
-def read_tensor_bundle(prefix: str, verify_crc: bool = True) -> dict:
-    """`prefix.index` + `prefix.data-*` -> {key: ndarray}.  String tensors (the object graph) are skipped."""
+def read_tensor_bundle(prefix: str, verify_crc: bool = True, want=None) -> dict:
+    """`prefix.index` + `prefix.data-*` -> {key: ndarray}.  String tensors (the object graph) are skipped; `want(key) -> bool`
+    selects the tensors that are read and CRC-checked at all (a ModelCheckpoint file also carries the Adam slots of every
+    variable: twice the model again, which load_weights has no use for)."""
     table = read_table(str(prefix) + ".index", verify_crc)
     header = _parse_proto(table.get(b"", b""))
     num_shards = header.get(1, [1])[0]
@@ -225,6 +270,8 @@ def read_tensor_bundle(prefix: str, verify_crc: bool = True) -> dict:
         dtype = e.get(1, [0])[0]
         if dtype not in _DTYPES:
             continue                                    # DT_STRING etc.: nothing this build needs
+        if want is not None and not want(key.decode()):
+            continue
         dims = [_parse_proto(d).get(1, [0])[0] for d in _parse_proto(e.get(2, [b""])[0]).get(2, [])]
         shard, off, size = e.get(3, [0])[0], e.get(4, [0])[0], e.get(5, [0])[0]
         if 7 in e:
@@ -348,7 +395,7 @@ def flat_from_tensors(tensors: dict, cfg: RvConfig) -> dict:
 
 
 def flat_from_checkpoint(prefix: str, cfg: RvConfig) -> dict:
-    return flat_from_tensors(read_tensor_bundle(prefix), cfg)
+    return flat_from_tensors(read_tensor_bundle(prefix, want=lambda k: _classify(k) is not None), cfg)
 
 
 def is_tf_checkpoint(path: str) -> bool:

@@ -18,7 +18,7 @@ LIMITS = {
     r"k_dec_persistILi5ELi11ELi1ELi0E": 64,      # C3: Luong, beam 5, T_m <= 352 (36 B today)
     r"k_dec_persistILi5ELi8ELi1ELi0E": 0,        # R: T_m <= 256
     r"k_dec_persistILi5ELi11ELi1ELi1E": 64,      # C3 with Bahdanau (28 B today)
-    r"k_dec_persistILi5ELi11ELi1ELi2E": 128,     # C3 with the attention on the matrix pipe (100 B today: six fragments parked in the prologue)
+    r"k_dec_persistILi5ELi11ELi1ELi2E": 24,      # C3 with the attention on the matrix pipe (20 B today; 100 B in round 2)
     r"k_dec_persistILi5ELi8ELi1ELi2E": 0,        # R
     r"k_lstm_rec_projILi2ELi[012]EE": 0,         # C3 fused recurrence + projection (f32, split-bf16 and split-f16 MFMA forms)
     r"k_gemm_mem_split3": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
