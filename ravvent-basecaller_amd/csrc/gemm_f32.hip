@@ -426,7 +426,11 @@ void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int nc
   static const int dbg_env = getenv("RV_GEMM_DBG") ? atoi(getenv("RV_GEMM_DBG")) : 0;
   dbg = dbg_env;
 #endif
-  static const bool old_form = getenv("RV_GEMM_FORM3") != nullptr;      // A/B timing of the slab-streaming form (same results)
+  bool old_form = false;
+#ifdef RV_GEMM_DIAG
+  static const bool form3_env = getenv("RV_GEMM_FORM3") != nullptr;     // A/B timing of the slab-streaming form (diagnostic builds only)
+  old_form = form3_env;
+#endif
   // ncb == 1 (the attention-memory projection, N = 256) stays on form (3): with two column halves a workgroup would load its 128 KB of
   // weights for some twenty 32-row tiles, and the load shows (0.056 vs 0.052 ms at C3)
   if (!old_form && !dbg && ncb > 1) {

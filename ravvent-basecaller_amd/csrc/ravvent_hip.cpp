@@ -702,7 +702,9 @@ int alloc_slab_buffers(RvContext* h) {
   TRY(dalloc(h, &h->keys, B * Tm * RV_U));
   TRY(dalloc(h, &h->mem2, B * Tm * RV_E));
   DecState& d = h->dec_st;
+#ifdef RV_DIAG   // timing ablations that INVALIDATE results: only in `make diag` builds (libravvent_hip_diag.so), never in the product library
   if (const char* e = getenv("RV_ATT_STOP")) d.dbg_stop = atoi(e);
+#endif
   if (getenv("RV_REC_STAMPS")) { TRY(dalloc(h, &h->rec_ts, 24)); h->rec_ts_layer = atoi(getenv("RV_REC_STAMPS")) == 2 ? 1 : 0; }
   if (getenv("RV_DBG_STAMPS")) TRY(dalloc(h, &d.dbg_ts, 16));   // diagnostic builds: in-kernel phase stamps   // timing ablation only; results are invalid when set
   d.depth = c.dec_depth; d.ls_xh = N * RV_E; d.ls_c = N * RV_U;
@@ -834,7 +836,9 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wp, (size_t)2 * (c.enc_depth - 1) * 2 * RV_E * RV_G));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wh, (size_t)2 * (c.enc_depth - 1) * 2 * RV_WH_SLOT));
   if (c.enc_depth > 1) TRY(dalloc(h, &h->d_Wsb, (size_t)2 * (c.enc_depth - 1) * 2 * 3 * RV_E * RV_G));
+#ifdef RV_DIAG
   if (const char* e = getenv("RV_DBG_ROLE")) h->dbg_role = atoi(e);
+#endif
   TRY(dalloc(h, &h->d_WmemT, (size_t)RV_U * RV_E));
   bind_weights(h);
   TRY(alloc_slab_buffers(h));
