@@ -1,5 +1,6 @@
 """One-off stress: random shapes / beams / depths, persistent decode vs per-step kernels (tokens equal, scores within 1e-4),
-fused vs unfused projection, greedy included.  usage: python tools/stress_paths.py [n_cases]"""
+matrix-pipe recurrence (default) vs packed-FMA recurrence with fused / unfused projection, greedy included; and the asynchronous calls
+(three slabs in flight) byte-identical to the synchronous call.  usage: python tools/stress_paths.py [n_cases]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,13 +22,20 @@ for case in range(n):
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=case, max_raw_pad=min(15, T_r - 1), max_event_pad=min(10, T_e - 1))
     x = (raw, ev) if mode == "joint" else (raw if mode == "raw" else ev)
     out = {}
-    for key, (persist, fuse) in {"pf": (1, 1), "sf": (0, 1), "pu": (1, 0)}.items():
-        bc.set_option("persistent_decode", persist); bc.set_option("fused_projection", fuse)
+    for key, (persist, fuse, wide) in {"pf": (1, 1, 1), "sf": (0, 1, 1), "pu": (1, 0, 0), "fm": (1, 1, 0)}.items():
+        bc.set_option("persistent_decode", persist); bc.set_option("fused_projection", fuse); bc.set_option("wide_recurrence", wide)
         t, s = bc.beam_search_prediction(x, W, L)
+        if key == "pf":      # asynchronous calls: the same slab three times in flight, each byte-identical to the synchronous result
+            bc.set_async_depth(3)
+            for ta, sa in bc.beam_search_stream([x, x, x], W, L):
+                if ta.shape != t.shape or not (ta.numpy() == t.numpy()).all() or not np.array_equal(sa.numpy(), s.numpy()):
+                    bad += 1
+                    print("ASYNC MISMATCH", case, mode, att, enc_d, dec_d, B, T_r, T_e, W, L)
+                    break
         g, lg = bc.greedy_search_prediction(x, L)
         out[key] = (t.numpy().copy(), s.numpy().copy(), g.numpy().copy(), lg.numpy().copy())
     ok = True
-    for other in ("sf", "pu"):
+    for other in ("sf", "pu", "fm"):
         a, b = out["pf"], out[other]
         same = a[0].shape == b[0].shape and (a[0] == b[0]).all(axis=1).mean() >= 0.98 if a[0].size else a[0].shape == b[0].shape
         rows = (a[0] == b[0]).all(axis=1) if a[0].size and a[0].shape == b[0].shape else np.zeros(0, bool)
