@@ -301,15 +301,21 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
 // (4) WEIGHT-STATIONARY form (round 3; what launch_gemm_split_blocks runs).  Probes of form (3) on the encoder input projection
 // (C3: M = 76,800, N = 1,024; tools/gemm_probe.sh) showed its parts ADD -- slab staging + barriers 0.054 ms, MFMAs + 0.098, C stores
 // + 0.05: one workgroup per CU whose six waves meet at a barrier every k-step leaves nothing to overlap with.  Here a workgroup
-// keeps ONE half column block (128 columns x K = 256, two f16 parts: 128 KB) in LDS for its whole life and its eight waves
-// (two per SIMD) run free: a wave takes 32-row tiles of its workgroup's row group, loads its own A rows straight into registers
-// (four stream positions in flight: a 4-slot ring, 8 k-steps per tile, so slot = k-step % 4 at compile time, across tile
-// boundaries too), splits them, multiplies against the resident fragments (64 accumulator registers: 32 rows x 128 columns) and
-// stores -- no barrier after the weight load, so one wave's loads, conversions and stores run under the other wave's MFMAs.
-// The vector-memory counter retires in order and counts stores: with four positions in flight the loads a new tile needs in its
-// first four k-steps were issued BEFORE the previous tile's stores, which therefore drain in the background.
+// keeps ONE half column block (128 columns x K = 256, two f16 parts: 128 KB) in LDS for its whole life and its waves (three per
+// SIMD) run free: a wave takes 32-row tiles of its workgroup's row group, loads its own A rows straight into registers (RING stream
+// positions in flight: slot = k-step % RING at compile time, 8 k-steps per tile, across tile boundaries too), splits them, multiplies
+// against the resident fragments (64 accumulator registers: 32 rows x 128 columns) and stores -- no barrier after the weight
+// load, so one wave's loads, conversions and stores run under the other waves' MFMAs.  (The vector-memory counter retires in
+// order and counts stores: a load issued after a tile's 16 stores cannot be waited for without draining them -- the other waves
+// of the SIMD cover that wait.)
+// Twelve waves (three per SIMD, 168 VGPRs) with two stream positions in flight each: measured 0.148 ms on the C3 input projection
+// against 0.156-0.160 for eight waves with two or four positions (256 VGPRs): the third wave per SIMD hides more of the A-load and
+// store latency than the deeper ring does.  (-DRV_WS_THREADS=512 -DRV_WS_RING=4 rebuilds the eight-wave form.)
 #ifndef RV_WS_THREADS
-#define RV_WS_THREADS 512
+#define RV_WS_THREADS 768
+#endif
+#ifndef RV_WS_RING
+#define RV_WS_RING 2       // A stream positions in flight per wave (a divisor of 8)
 #endif
 // Workgroup id -> (row group, column half): the 2 ncb workgroups that share a row group have the same id % 8, i.e. sit on one
 // XCD and run at the same time, so the row group's A rows come from HBM once and from that XCD's L2 otherwise.
@@ -338,12 +344,14 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
   const int tstride = NW * nrg;
   int t = rg + nrg * wave;
   if (t >= ntile) return;
-  float4 ar[4][2][2];                                                // [slot][row tile][half]
+  constexpr int RING = RV_WS_RING;
+  float4 ar[RING][2][2];                                             // [slot][row tile][half]
 #define RV_WS_LOAD(tile_, ks_, slot_) do { \
     _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) { \
       const float* ap_ = A + (size_t)min((tile_) * 32 + 16 * m_ + l16, M - 1) * RV_E + 8 * q + 32 * (ks_); \
       ar[slot_][m_][0] = *reinterpret_cast<const float4*>(ap_); ar[slot_][m_][1] = *reinterpret_cast<const float4*>(ap_ + 4); } } while (0)
-  RV_WS_LOAD(t, 0, 0); RV_WS_LOAD(t, 1, 1); RV_WS_LOAD(t, 2, 2); RV_WS_LOAD(t, 3, 3);
+#pragma unroll
+  for (int p0 = 0; p0 < RING; ++p0) RV_WS_LOAD(t, p0, p0);
   for (; t < ntile; t += tstride) {
     const int tn = t + tstride < ntile ? t + tstride : t;            // (the last tile re-reads four of its own k-steps: L2 hits, dropped)
     f4v acc[2][8];
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
       h8 ah[2], al[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const float4 x0 = ar[ks & 3][m][0], x1 = ar[ks & 3][m][1];
+        const float4 x0 = ar[ks % RING][m][0], x1 = ar[ks % RING][m][1];
         const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
         }
       }
 #ifndef RV_WS_NOALOAD   // (diagnostic builds: results invalid)
-      if (ks < 4) RV_WS_LOAD(t, ks + 4, ks & 3); else RV_WS_LOAD(tn, ks - 4, ks & 3);     // stream position + 4, into the slot just consumed
+      if (ks + RING < 8) RV_WS_LOAD(t, ks + RING, ks % RING); else RV_WS_LOAD(tn, ks + RING - 8, ks % RING);     // stream position + RING, into the slot just consumed
 #endif
       const char* bs = Bl + ks * 16384 + lane * 16;
       // Two column tiles at a time: four accumulators (2 row tiles x 2 column tiles) take the three part products in turn, so that
@@ -434,10 +442,10 @@ void launch_gemm_split_blocks(const float* A, int M, const uint16_t* img, int nc
   // ncb == 1 (the attention-memory projection, N = 256) stays on form (3): with two column halves a workgroup would load its 128 KB of
   // weights for some twenty 32-row tiles, and the load shows (0.056 vs 0.052 ms at C3)
   if (!old_form && !dbg && ncb > 1) {
-    // row groups: 8 k with 8 k x 2 ncb ~ 256 workgroups, but no more groups than there are 8-tile bundles of work
-    const int nch = 2 * ncb, ntile = (M + 31) / 32;
+    // row groups: 8 k with 8 k x 2 ncb ~ 256 workgroups, but no more groups than there is work for their waves
+    const int nch = 2 * ncb, ntile = (M + 31) / 32, nw = RV_WS_THREADS / 64;
     int k = 256 / (8 * nch);
-    while (k > 1 && 8 * (k - 1) * 8 >= ntile) --k;                // keep every wave of every workgroup busy with at least one tile where possible
+    while (k > 1 && 8 * (k - 1) * nw >= ntile) --k;               // keep every wave of every workgroup busy with at least one tile where possible
     const int nrg = 8 * k;
     hipLaunchKernelGGL(k_gemm_ws, dim3(nrg * nch), dim3(RV_WS_THREADS), GEMM_WS_LDS, s, A, M, img, ncb, bias, C, ldc, nrg);
     return;
