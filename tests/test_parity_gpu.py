@@ -792,7 +792,14 @@ def test_asynchronous_calls_match_synchronous(rv, depth, wide):
         assert bc.collect(t_empty)[0].shape[0] == 0
     if mid is not None:
         assert same(mid, ref[1])
-    bc.close()
+    # a refused submit (slab larger than the handle's max_batch) leaves no context busy; closing a handle with calls in flight waits for them
+    big = rv.synthetic.make_slab(41, 120, 20, seed=1)[:2]
+    for _ in range(depth + 1):
+        with pytest.raises(rv._capi.RavventHipError, match="outside"):
+            bc.submit_beam_search(big, 5, 24)
+    tickets = [bc.submit_beam_search(slabs[i], 5, 24) for i in range(depth)]
+    assert same(bc.collect(tickets[0]), ref[0])
+    bc.close()                                                  # depth - 1 slabs still in flight
 
 
 def test_device_outputs_are_fresh_per_call(rv):
