@@ -294,12 +294,19 @@ class Basecaller:
         sub = self.submit_calls if calls else self.submit_beam_search
         col = self.collect_calls if calls else self.collect
         queue = []
-        for x in slabs:
-            if len(queue) >= depth:
+        try:
+            for x in slabs:
+                if len(queue) >= depth:
+                    yield col(queue.pop(0))
+                queue.append(sub(x, beam_width, max_output_len))
+            while queue:
                 yield col(queue.pop(0))
-            queue.append(sub(x, beam_width, max_output_len))
-        while queue:
-            yield col(queue.pop(0))
+        finally:                       # a consumer that stops early (or an error): no ticket may stay uncollected on the handle
+            while queue:
+                try:
+                    col(queue.pop(0))
+                except Exception:
+                    pass
 
     def greedy_search_prediction(self, input_data, max_output_len):
         """basecaller.py:317-330 -> (sample_id [B,S] int32, rnn_output logits [B,S,V] f32)."""

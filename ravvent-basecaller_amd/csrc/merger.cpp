@@ -70,7 +70,7 @@ inline double affine(int length, double open, double extend) {   // calc_affine_
 __attribute__((target_clones("avx512f", "avx2", "default")))
 static double fill_diagonals(int lenA, int lenB, int nl, double first_gap, double extend, double open2, const int* __restrict__ ia,
                              const int* __restrict__ ibr, const double* __restrict__ mtab, int mstride, double* __restrict__ work,
-                             double* __restrict__ score, int* __restrict__ trace) {
+                             double* __restrict__ score, int* __restrict__ trace, double* __restrict__ diag_max) {
   // work: 8 arrays of nl + 8 doubles; element r of an array lives at [8 + r], so that [r - 1] of row 0 is addressable
   const int ws = nl + 8;
   double* hbuf[3] = {work + 8, work + 8 + ws, work + 8 + 2 * ws};       // scores of three consecutive diagonals, rotating
@@ -122,7 +122,10 @@ static double fill_diagonals(int lenA, int lenB, int nl, double first_gap, doubl
     }
     // best score = max over the clipped cells (it starts at 0 in the reference too); kept out of the loop above: without fast-math
     // the compare-select maximum is not a reduction the vectoriser accepts.  Rows without a cell on diagonal d hold 0, the border value.
-    for (int r = r_lo; r <= r_hi; ++r) local_max = local_max > sd[r] ? local_max : sd[r];
+    double dm = 0;
+    for (int r = r_lo; r <= r_hi; ++r) dm = dm > sd[r] ? dm : sd[r];
+    diag_max[d] = dm;                                      // find_start only looks at diagonals that reach the best score
+    local_max = local_max > dm ? local_max : dm;
   }
   return local_max;
 }
@@ -137,7 +140,7 @@ struct Aligner {
   ScoreSet sc;
   std::vector<double> score;     // (lenA+1) x (lenB+1)
   std::vector<int> trace;        // -1 = None (border)
-  std::vector<double> dbuf, itab;  // per-diagonal work arrays of fill(); identity match table
+  std::vector<double> dbuf, itab, dmax;  // per-diagonal work arrays of fill(); identity match table; best score of each diagonal
   std::vector<int> tbuf, ia, ib;
   std::vector<Start> starts;
   double best = 0;
@@ -156,8 +159,12 @@ struct Aligner {
     W = lenB + 1;
     NL = (lenA + 1 + 7) & ~7;
     const int nd = lenA + lenB + 1;
-    score.assign((size_t)nd * NL, 0.0);                     // borders and cells off the matrix: score 0, trace None
-    trace.assign((size_t)nd * NL, -1);
+    // (no clearing: the sweep writes every cell and border the traceback can reach -- rows r_lo - 1 .. r_hi + 1 of each diagonal, row 0
+    //  while it is a border -- and find_start only reads the valid rows of a diagonal; diagonals 0 and 1 hold borders only)
+    if (score.size() < (size_t)nd * NL) { score.resize((size_t)nd * NL); trace.resize((size_t)nd * NL); }
+    if (dmax.size() < (size_t)nd) dmax.resize(nd);
+    for (int i = 0; i < 2 * NL; ++i) { score[i] = 0.0; trace[i] = -1; }
+    dmax[0] = dmax[1] = 0.0;
     const double open = sc.open, extend = sc.extend;
     const double first_gap = affine(1, open, extend);
     const int ws = NL + 8;
@@ -187,7 +194,7 @@ struct Aligner {
       f[r] = affine(r, 2 * open, extend);                 // row state before column 1
       ga[r] = r == lenA ? 0.0 : first_gap; ea[r] = r == lenA ? 0.0 : extend;
     }
-    best = fill_diagonals(lenA, lenB, NL, first_gap, extend, 2 * open, ia.data(), ibr, tab, stride, dbuf.data(), score.data(), trace.data());
+    best = fill_diagonals(lenA, lenB, NL, first_gap, extend, 2 * open, ia.data(), ibr, tab, stride, dbuf.data(), score.data(), trace.data(), dmax.data());
   }
 
   void find_start(std::vector<Start>& st) {
@@ -195,12 +202,15 @@ struct Aligner {
     const double lim = best - 0.001;                       // cheap filter (twice the bucket width); candidates take the exact test below
     auto exact = [&](double s) { const double d = s > best ? s - best : best - s; return d * 1000 + 0.5 < 1.0; };   // rint(abs(s - best)) <= rint(0)
     if (lim > 0.0) {
-      // the usual case: a positive best score.  Cells off the matrix hold 0 < lim, so a flat scan of the diagonal-major storage finds
-      // the (few) candidates; they are then put into the row-major order in which the reference scans its matrix
-      const size_t n = (size_t)(lenA + lenB + 1) * NL;
-      const double* sp = score.data();
-      for (size_t i = 0; i < n; ++i)
-        if (sp[i] >= lim && exact(sp[i])) { const int r = (int)(i % NL), d = (int)(i / NL); st.push_back({sp[i], r, d - r}); }
+      // the usual case: a positive best score.  Only the diagonals whose maximum reaches it are scanned (their valid rows); the (few)
+      // candidates are then put into the row-major order in which the reference scans its matrix
+      for (int d = 2; d <= lenA + lenB; ++d) {
+        if (dmax[d] < lim) continue;
+        const int r_lo = d - lenB > 1 ? d - lenB : 1, r_hi = lenA < d - 1 ? lenA : d - 1;
+        const double* sp = score.data() + (size_t)d * NL;
+        for (int r = r_lo; r <= r_hi; ++r)
+          if (sp[r] >= lim && exact(sp[r])) st.push_back({sp[r], r, d - r});
+      }
       std::sort(st.begin(), st.end(), [](const Start& x, const Start& y) { return x.row != y.row ? x.row < y.row : x.col < y.col; });
       return;
     }

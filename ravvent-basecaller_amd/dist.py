@@ -169,6 +169,7 @@ def sharded_beam_search_stream(basecaller, slabs, beam_width: int, max_output_le
             tok, sc = basecaller.collect(call)
         return gather_calls(tok, sc, tok.shape[1], n, steps, end_token=end_token, group=group, device=dev)
 
+    # (a consumer that abandons the generator early leaves collective calls unmatched on the other ranks: iterate it to the end)
     for raw, event in slabs:
         n = (raw if raw is not None else event).shape[0]
         lo, hi = shard_range(n, rank, world)
