@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--recurrence", default="mx", choices=["mx", "fma", "auto"],
                     help="library option wide_recurrence: mx = matrix-pipe recurrence, 16 chunks per workgroup (library default); "
                          "fma = packed-FMA kernels; auto = per call by chunks in flight")
-    ap.add_argument("--depth", type=int, default=6, help="slabs in flight through the asynchronous calls (1..8); 0 = the synchronous call")
+    ap.add_argument("--depth", type=int, default=10, help="slabs in flight through the asynchronous calls (1..16); 0 = the synchronous call")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a fixed read of --read-chunks chunks per step, sharded over the GPUs")
     ap.add_argument("--read-chunks", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,7 +275,7 @@ def main():
     d_raw, d_ev = torch.from_numpy(raw).to(dev), torch.from_numpy(ev).to(dev)
     lo, hi = rv.dist.shard_range(n_global, rank, world)
 
-    depth = max(0, min(args.depth, 8))
+    depth = max(0, min(args.depth, 16))
     if depth:
         bc.set_async_depth(depth)
     bc.set_option("wide_recurrence", {"mx": 1, "fma": 0, "auto": -1}[args.recurrence])

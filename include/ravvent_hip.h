@@ -153,7 +153,7 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       the lower latency for ONE isolated slab of <= 256 chunks (C3 shape: 1.40 vs 1.86 ms).  -1 = choose per call
  *                       by that rule -- fastest, but the two forms agree to f32 rounding only, so results then depend on the slab
  *                       size; with 1 or 0 a chunk's result never depends on the slab or shard it travels in),
- *          "async_depth" (1..8, default 2: contexts the rv_beam_search_submit* calls rotate through),
+ *          "async_depth" (1..16, default 2: contexts the rv_beam_search_submit* calls rotate through),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

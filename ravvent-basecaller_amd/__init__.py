@@ -9,10 +9,11 @@ There is no CPU fallback: without the HIP library the path raises.
 import os as _os
 
 # The asynchronous calls keep several slabs in flight, one HIP stream per slab context.  The ROCm runtime multiplexes a process's
-# streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with 4+ contexts two of them share a queue and serialise
-# (measured at the C3 shape: depth 4 -> 203 k chunks/s on 4 queues, 262 k on 8).  The variable is read when the HIP runtime
-# starts, i.e. at the process's first HIP call -- importing this package first is enough; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with more contexts than queues some share a queue and serialise
+# (measured at the C3 shape: depth 4 -> 203 k chunks/s on 4 queues, 262 k on 8; depth 10 -> 278 k on 8 queues, 317 k on 16).  The
+# variable is read when the HIP runtime starts, i.e. at the process's first HIP call -- importing this package first is enough;
+# an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .config import RvConfig  # noqa: F401
 from . import data_loader, utils, weights, synthetic, dist, evaluator, event_detection, checkpoint  # noqa: F401

@@ -209,7 +209,7 @@ class Basecaller:
 
     # ------------------------------------------------------------------ the hot path, several slabs in flight
     def set_async_depth(self, depth: int):
-        """Slab contexts the submit_* calls rotate through (1..8; default 2).  With several slabs in flight the GPU never idles
+        """Slab contexts the submit_* calls rotate through (1..16; default 2).  With several slabs in flight the GPU never idles
         at a slab boundary, and the encoder recurrences run 16 chunks per workgroup on the matrix pipe (option wide_recurrence)."""
         self.set_option("async_depth", int(depth))
         self.async_depth = int(depth)

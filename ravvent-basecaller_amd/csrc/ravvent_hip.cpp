@@ -23,7 +23,7 @@ struct LstmW { const float *W, *U, *b; };
 
 struct ProfEntry { double ms = 0; int64_t n = 0; };
 
-constexpr int RV_MAX_ASYNC = 8;
+constexpr int RV_MAX_ASYNC = 16;
 
 struct GraphKey {
   int B, W, Tm, L, greedy, taps, split;
