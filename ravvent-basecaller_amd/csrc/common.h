@@ -34,6 +34,9 @@ struct RecArgs {
   long long* dbg_ts;     // diagnostic builds (-DRV_REC_STAMPS, env RV_REC_STAMPS): [24] per-wave {busy, barrier-wait} cycle sums of workgroup (0,0)
   int tail_wave;         // layer 0 (F > 0), rows_per_block >= 2: the cell update runs on a ninth wave (k_lstm_rec_tw)
   int dbg_role;          // timing probe only (RV_DBG_ROLE): 1 = projection waves skip their math, 2 = recurrence waves skip theirs
+  uint8_t* mask;         // matrix-pipe raw layer 0 only: also leaves utils.input_mask of its chunks at mask[b * mask_T + mask_t0 + t]
+  int mask_T, mask_t0;   //   (the window is in LDS anyway; saves the slab a launch).  null = not asked for
+  float pad;
 };
 // F in {0,1,5}; rows_per_block in {1,2,4,8}
 void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s);
@@ -48,7 +51,9 @@ void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s);
 bool lstm_rec_mx_window_fits(int T);
 hipError_t configure_mx_kernels();
 // xw [rows,2,512] = x [rows,F] . W_dir [F,512] + b_dir for a layer-0 encoder with F = 5 (or 1) input features, both directions
-void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw, hipStream_t s);
+// mask != null: also writes utils.input_mask of the rows, mask[(r / T) * mask_T + mask_t0 + r % T] = all(x[r, :] != pad)
+void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw,
+                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s);
 hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the recurrence kernels; first error or hipSuccess
 // layer 0 stages its chunks' whole input windows in LDS: does a window of T steps x F features fit with that many rows per workgroup?
 bool lstm_rec_window_fits(int F, int rows_per_block, int T);
@@ -128,6 +133,7 @@ struct DecState {
   uint8_t lut[RV_MAX_VOCAB];   // token id -> upper-case letter, 0 for tokens the string form drops
   int* chunk_steps;       // persistent decode: [B] steps each chunk ran (nullptr on the per-step graph path)
   int* S_dev;             // [8]: [0] = S of the whole slab, [1+g] = S of sub-slab g
+  int* S_host;            // device address of the host-mapped pinned word the call's S is left in (no copy launch for 4 bytes)
   // persistent decode, Luong, one cell: scores and context as split-f16 MFMAs.  Scales: powers of two that bring the largest
   // value a key / a U' element can take (from the weights; |enc_out| <= 1) into [2^13, 2^14); descale = 2^-14 / scale (the query
   // and the alignments are scaled by 2^14)
@@ -153,7 +159,7 @@ bool dec_persist_supported(const DecState& d);
 void launch_dec_persist(const DecState& d, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
                         const float* bdec /*[512]*/, const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s);
 void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
-struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; };
+struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; int* S_host; };
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s);   // S_dev[0] = max_g S_g, S_dev[1+g] = S_g
 
 // ---------------------------------------------------------------- device math helpers

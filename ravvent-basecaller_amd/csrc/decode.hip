@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens
     int m = 0;
     for (int i = tid; i < d.B; i += 64) m = max(m, d.chunk_steps[i]);
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if (tid == 0) { s_S = m; if (b == 0) { d.S_dev[0] = m; d.S_dev[1] = m; } }
+    if (tid == 0) { s_S = m; if (b == 0) { d.S_dev[0] = m; d.S_dev[1] = m; d.S_host[0] = m; } }
     __syncthreads();
   }
   const int S = d.chunk_steps ? s_S : d.S_dev[0], So = d.chunk_steps ? d.chunk_steps[b] : d.S_dev[1 + d.part];
@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
     if (lane == 0) p.S_dev[1 + g] = Sg;
     S = max(S, Sg);
   }
-  if (lane == 0) p.S_dev[0] = S;
+  if (lane == 0) { p.S_dev[0] = S; p.S_host[0] = S; }
 }
 
 }  // namespace

@@ -61,7 +61,12 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
       wxs[tid] = a.W[dir][tid]; wxs[RV_G + tid] = a.bias[dir][tid];
       for (int r = 0; r < RV_MX_ROWS; ++r) {
         const int b = min(b0 + r, a.B - 1);
-        for (int i = tid; i < T; i += 512) xs[r * T + i] = a.x[(size_t)b * T + i];
+        const bool wm = a.mask && dir == 0 && b0 + r < a.B;     // utils.input_mask of the raw part (utils.py:26-32), once per chunk
+        for (int i = tid; i < T; i += 512) {
+          const float v = a.x[(size_t)b * T + i];
+          xs[r * T + i] = v;
+          if (wm) a.mask[(size_t)b * a.mask_T + a.mask_t0 + i] = v != a.pad ? 1 : 0;
+        }
       }
     }
   }
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 // xw [B*T, 2, 512].  One thread = 4 gate columns of one row; HBM-bound on its output (4 KB per chunk-timestep).
 template <int F>
 __global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ x, int rows, const float* __restrict__ W0, const float* __restrict__ b0,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ xw) {
+                                                       const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ xw,
+                                                       uint8_t* __restrict__ mask, int T, int mask_T, int mask_t0, float pad) {
   const int c4 = threadIdx.x & 127, dir = threadIdx.x >> 7;
   const float* W = dir ? W1 : W0;
   const float* b = dir ? b1 : b0;
@@ -174,12 +180,15 @@ __global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ 
   const float4 bv = *reinterpret_cast<const float4*>(b + 4 * c4);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     float4 acc = bv;
+    bool real = true;                                            // utils.input_mask (utils.py:26-32): all features != pad
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       const float xv = x[(size_t)r * F + f];
+      real = real && xv != pad;
       acc.x = fmaf(xv, wr[f].x, acc.x); acc.y = fmaf(xv, wr[f].y, acc.y); acc.z = fmaf(xv, wr[f].z, acc.z); acc.w = fmaf(xv, wr[f].w, acc.w);
     }
     *reinterpret_cast<float4*>(xw + ((size_t)r * 2 + dir) * RV_G + 4 * c4) = acc;
+    if (mask && threadIdx.x == 0) mask[(size_t)(r / T) * mask_T + mask_t0 + r % T] = real ? 1 : 0;
   }
 }
 
@@ -204,8 +213,9 @@ void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s) {
   else hipLaunchKernelGGL((k_lstm_rec_mx<0>), grid, dim3(512), mx_lds_bytes(0, a.T), s, a);
 }
 
-void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw, hipStream_t s) {
+void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw,
+                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s) {
   const int grid = rows < 4096 ? rows : 4096;
-  if (F == 5) hipLaunchKernelGGL((k_inproj_small<5>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw);
-  else hipLaunchKernelGGL((k_inproj_small<1>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw);
+  if (F == 5) hipLaunchKernelGGL((k_inproj_small<5>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad);
+  else hipLaunchKernelGGL((k_inproj_small<1>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad);
 }

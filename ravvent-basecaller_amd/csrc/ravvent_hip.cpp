@@ -303,13 +303,15 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       if (l == 0 && F == 1) {
         a.x = x;
         for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
+        a.mask = h->mask; a.mask_T = Tm; a.mask_t0 = t_off; a.pad = h->cfg.padding_value;   // the layer-0 kernels leave the input mask too
         Scope sc(h, "lstm_rec_raw_l0", s);
         launch_lstm_rec_mx(a, 1, s);
         continue;
       }
       if (l == 0) {
         Scope sc(h, e == 0 ? "inproj_raw_l0" : "inproj_event_l0", s);
-        launch_inproj_small(x, B * T, F, h->enc[e][0][0].W, h->enc[e][0][0].b, h->enc[e][0][1].W, h->enc[e][0][1].b, h->xw[e], s);
+        launch_inproj_small(x, B * T, F, h->enc[e][0][0].W, h->enc[e][0][0].b, h->enc[e][0][1].W, h->enc[e][0][1].b, h->xw[e],
+                            h->mask, T, Tm, t_off, h->cfg.padding_value, s);
       } else {
         Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event", s);
         launch_gemm_split_blocks(h->act[e][(l - 1) & 1], B * T, h->d_Wx16 + (size_t)(e * (depth - 1) + (l - 1)) * RV_WX16_SLOT, 4,
@@ -435,14 +437,15 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   // The mask is first read by the memory set-up / the decode: it runs on a side stream beside the encoders instead of in front
   // of them (profiling modes keep it on the main stream so that its events pair up).
   // (with several slabs in flight the other slabs fill the chip: one stream per context then, no fork / join)
-  const bool mask_aside = (h->opt_profile == 0 || h->opt_profile == 3) && h->inflight_hint <= 1 && !h->parent;
+  // The matrix-pipe layer-0 kernels write it themselves (they read every input sample anyway): no launch at all then.
+  const bool mask_aside = !h->lwide && (h->opt_profile == 0 || h->opt_profile == 3) && h->inflight_hint <= 1 && !h->parent;
   if (mask_aside) {
     hipStream_t sm = side_stream(h, 2);
     HIPCHK(h, hipEventRecord(h->ev_fork, s));
     HIPCHK(h, hipStreamWaitEvent(sm, h->ev_fork, 0));     // inputs (H2D copies on s) are in place
     launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, sm);
     HIPCHK(h, hipEventRecord(h->ev_join[2], sm));
-  } else {
+  } else if (!h->lwide) {
     Scope sc(h, "input_mask"); launch_input_mask(xr, xe, B, T_r, T_e, c.padding_value, h->mask, s);
   }
   // The two encoders are independent until the time-axis concat (basecaller.py:400-405).
@@ -533,7 +536,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   const int Wd = d.W;
   DecState part[4];
   DecParts parts{};
-  parts.n = nsplit; parts.steps = steps; parts.S_dev = d.S_dev;
+  parts.n = nsplit; parts.steps = steps; parts.S_dev = d.S_dev; parts.S_host = d.S_host;
   for (int g = 0; g < nsplit; ++g) {
     const size_t b0 = (size_t)B * g / nsplit, b1 = (size_t)B * (g + 1) / nsplit;
     DecState& p = part[g];
@@ -620,7 +623,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
       launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s);
     }
   }
-  HIPCHK(h, hipMemcpyAsync(h->pin_S, d.S_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  // (S reaches the host through d.S_host: the finalize / reduce kernel stores it straight into the mapped pinned word)
   if (!dev_out && !calls) {
     HIPCHK(h, hipMemcpyAsync(h->pin_tok, tk, sizeof(int32_t) * B * steps, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_out2, o2, sizeof(float) * B * steps * (greedy ? V : 1), hipMemcpyDeviceToHost, s));
@@ -735,7 +738,8 @@ int alloc_slab_buffers(RvContext* h) {
   HIPTRY(hipHostMalloc((void**)&h->pin_ev, std::max<size_t>(B * Te * 5, 1) * sizeof(float), hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_tok, B * L * sizeof(int32_t), hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_out2, B * L * V * sizeof(float), hipHostMallocDefault));
-  HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocDefault));
+  HIPTRY(hipHostMalloc((void**)&h->pin_S, sizeof(int), hipHostMallocMapped));
+  HIPTRY(hipHostGetDevicePointer((void**)&d.S_host, h->pin_S, 0));
   TRY(dalloc(h, &h->d_bases, B * L));
   TRY(dalloc(h, &h->d_probs, B * L));
   TRY(dalloc(h, &h->d_clen, B));
