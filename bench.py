@@ -460,6 +460,17 @@ def main():
         if roof["bound"] == "mfma" and "peak_note" not in roof:
             roof["peak_note"] = PEAK_NOTE
         roof_iso = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass of synchronous calls, the launch alone on the chip")
+        if depth and name in prof_dec and roof.get("frac") and roof_iso.get("frac"):
+            # with D slabs in flight the launch's span covers the other slabs' kernels that share the chip with it: `frac` (the
+            # contract's flops / live span) then says how long a launch waits, not how well the kernel runs.  Two readings beside it:
+            # the launch alone on the chip, and the timed region's step time x this kernel's share of the slab's CU-time
+            roof["frac_alone"] = roof_iso["frac"]
+            chip_ms = (dt / args.steps) * 1e3 / max(slabs_per_step, 1) * roof["share_of_cu_time"]
+            roof["chip_time_ms_per_launch"] = round(chip_ms, 5)
+            roof["frac_chip_time"] = round(roof["flops_per_launch"] / (chip_ms * 1e-3) / 1e12 / roof["peak"], 4) if roof.get("flops_per_launch") else None
+            roof["span_note"] = (f"avg_launch_ms is the live span with {depth} slabs in flight (other slabs' kernels run on the same CUs "
+                                 "inside it); frac_alone = the launch alone on the chip (roofline_isolated); frac_chip_time = "
+                                 "FLOPs / (timed ms per slab x share_of_cu_time)")
         top2 = [roof_of(k, per_slab[k], 10, "hipEvents, untimed pass, the launch alone on the chip") for k in order[1:3]
                 if algorithmic_flops(k, Bk, T_r, T_e, W, S)]
         for r, k in zip(top2, [k for k in order[1:3] if algorithmic_flops(k, Bk, T_r, T_e, W, S)]):

@@ -67,67 +67,95 @@ inline double affine(int length, double open, double extend) {   // calc_affine_
 // with plain vector stores -- and the traceback reads cell (r, c) at [(r + c) * nl + r].
 // (Round 3: the row-major stores, per-diagonal trip counts and the gather of the first form cost 9 of the 13 us a chunk pair took
 //  on a 2.1 GHz Xeon -- more than the GPU needs for the chunk.)
-__attribute__((target_clones("avx512f", "avx2", "default")))
-static double fill_diagonals(int lenA, int lenB, int nl, double first_gap, double extend, double open2, const int* __restrict__ ia,
-                             const int* __restrict__ ibr, const double* __restrict__ mtab, int mstride, double* __restrict__ work,
-                             double* __restrict__ score, int* __restrict__ trace, double* __restrict__ diag_max) {
+// MATRIX: letter codes 0..3 and mrow[k][r] = m[letter of row r][k] (four row-indexed arrays, stride mstride): the substitution score is
+// picked by three selects on the column's code.  Identity scoring (the default score set): arbitrary codes, equal -> match, no table at all.
+// One group of 8 rows of one diagonal.  Every array comes in as a restrict parameter and the trip count is fixed, so the compiler
+// emits straight vector code: no run-time overlap checks, no scalar remainder (they were most of the instructions of the sweep
+// when the diagonal was one loop over rotating buffer pointers).
+template <bool MATRIX>
+__attribute__((always_inline)) static inline void diag_group(
+    int r0, int r_lo, int r_hi, int r_lastcol, double first_gap, double extend, double match, double mismatch,
+    const double* __restrict__ h1, const double* __restrict__ h2, double* __restrict__ hn, const double* __restrict__ e1, double* __restrict__ en,
+    double* __restrict__ f, const double* __restrict__ ga, const double* __restrict__ ea, const int* __restrict__ ia, const int* __restrict__ ibd,
+    const double* __restrict__ m0, const double* __restrict__ m1, const double* __restrict__ m2, const double* __restrict__ m3,
+    double* __restrict__ sd, int* __restrict__ td, double* __restrict__ lane_max) {
+#pragma clang loop vectorize(enable) vectorize_width(8) interleave(disable)
+  for (int k = 0; k < 8; ++k) {
+    const int r = r0 + k;
+    const bool valid = r >= r_lo && r <= r_hi;
+    const int cb = ibd[r];
+    const double mm = MATRIX ? (cb == 0 ? m0[r] : cb == 1 ? m1[r] : cb == 2 ? m2[r] : m3[r]) : (ia[r] == cb ? match : mismatch);
+    const double nogap = h2[r - 1] + mm;
+    const double row_open = h1[r] + ga[r], row_extend = f[r] + ea[r];
+    const double rs = row_open > row_extend ? row_open : row_extend;
+    const bool lastcol = r == r_lastcol;               // column lenB: free end gaps in B
+    const double col_open = h1[r - 1] + (lastcol ? 0.0 : first_gap), col_extend = e1[r - 1] + (lastcol ? 0.0 : extend);
+    const double cs = col_open > col_extend ? col_open : col_extend;
+    double b = cs > rs ? cs : rs;
+    b = nogap > b ? nogap : b;
+    const double hv = valid ? (b < 0 ? 0.0 : b) : 0.0;
+    f[r] = valid ? rs : f[r]; en[r] = cs; hn[r] = hv;
+    // pairwise2.rint(x) = int(x * 1000 + 0.5); rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y))
+    const int ro = (int)(row_open * 1000 + 0.5), re = (int)(row_extend * 1000 + 0.5);
+    const int co = (int)(col_open * 1000 + 0.5), ce = (int)(col_extend * 1000 + 0.5), ng = (int)(nogap * 1000 + 0.5);
+    const int rr = ro > re ? ro : re, cr = co > ce ? co : ce;
+    int br = rr > cr ? rr : cr; br = ng > br ? ng : br;
+    int t = ng == br ? 2 : 0;
+    t += rr == br ? (ro == rr ? 1 : 0) + (re == rr ? 8 : 0) : 0;
+    t += cr == br ? (co == cr ? 4 : 0) + (ce == cr ? 16 : 0) : 0;
+    sd[r] = hv; td[r] = valid ? t : -1;
+    lane_max[k] = lane_max[k] > hv ? lane_max[k] : hv;   // per lane, not a reduction: rows without a cell hold 0, the border value
+  }
+}
+
+template <bool MATRIX>
+__attribute__((always_inline)) static inline double fill_diagonals_body(
+                             int lenA, int lenB, int nl, double first_gap, double extend, double open2, const int* __restrict__ ia,
+                             const int* __restrict__ ibr, const double* __restrict__ mrow, int mstride, double match, double mismatch,
+                             double* __restrict__ work, double* __restrict__ score, int* __restrict__ trace, double* __restrict__ diag_max) {
   // work: 8 arrays of nl + 8 doubles; element r of an array lives at [8 + r], so that [r - 1] of row 0 is addressable
   const int ws = nl + 8;
   double* hbuf[3] = {work + 8, work + 8 + ws, work + 8 + 2 * ws};       // scores of three consecutive diagonals, rotating
   double* ebuf[2] = {work + 8 + 3 * ws, work + 8 + 4 * ws};             // column states of two
-  double* __restrict__ f = work + 8 + 5 * ws;
-  const double* __restrict__ ga = f + ws;
-  const double* __restrict__ ea = ga + ws;
+  double* f = work + 8 + 5 * ws;
+  const double* ga = f + ws;
+  const double* ea = ga + ws;
+  const double* m0 = mrow, *m1 = mrow + mstride, *m2 = mrow + 2 * mstride, *m3 = mrow + 3 * mstride;
   double local_max = 0;
   for (int d = 2; d <= lenA + lenB; ++d) {
     const int r_lo = d - lenB > 1 ? d - lenB : 1, r_hi = lenA < d - 1 ? lenA : d - 1, r_lastcol = d - lenB;
-    // (block-scope restrict: the five arrays of a diagonal are distinct -- without it the loop below does not vectorise)
-    const double* __restrict__ h1 = hbuf[(d + 2) % 3];     // diagonal d-1
-    const double* __restrict__ h2 = hbuf[(d + 1) % 3];     // diagonal d-2
-    double* __restrict__ hn = hbuf[d % 3];
-    double* __restrict__ e1 = ebuf[(d + 1) & 1];
-    double* __restrict__ en = ebuf[d & 1];
+    const double* h1 = hbuf[(d + 2) % 3];     // diagonal d-1
+    const double* h2 = hbuf[(d + 1) % 3];     // diagonal d-2
+    double* hn = hbuf[d % 3];
+    double* e1 = ebuf[(d + 1) & 1];
+    double* en = ebuf[d & 1];
     {   // column state of column d-1 before row 1 (used by cell (1, d-1)): calc_affine_penalty(d-1, 2*open, extend)
       double p = open2 + extend * (d - 1); p -= extend; e1[0] = p;
     }
-    const int* __restrict__ ibd = ibr + (lenB - d);        // ibd[r] = code of B[d - r - 1]
-    double* __restrict__ sd = score + (size_t)d * nl;
-    int* __restrict__ td = trace + (size_t)d * nl;
-    // rows r_lo .. r_hi hold this diagonal's cells; the loop covers the enclosing 8-aligned window plus row r_hi + 1 (the border cell
+    const int* ibd = ibr + (lenB - d);        // ibd[r] = code of B[d - r - 1]
+    double* sd = score + (size_t)d * nl;
+    int* td = trace + (size_t)d * nl;
+    // rows r_lo .. r_hi hold this diagonal's cells; the sweep covers the enclosing 8-aligned window plus row r_hi + 1 (the border cell
     // (r, 0) of diagonal d = r, read as 0 by the next diagonals); rows outside it are never read again by a valid cell
     const int w_lo = r_lo & ~7, w_end = (r_hi + 9) & ~7, w_hi = w_end < nl ? w_end : nl;
-#pragma clang loop vectorize(enable) interleave(disable)
-    for (int r = w_lo; r < w_hi; ++r) {
-      const bool valid = r >= r_lo && r <= r_hi;
-      const double mm = mtab[ia[r] * mstride + ibd[r]];
-      const double nogap = h2[r - 1] + mm;
-      const double row_open = h1[r] + ga[r], row_extend = f[r] + ea[r];
-      const double rs = row_open > row_extend ? row_open : row_extend;
-      const bool lastcol = r == r_lastcol;               // column lenB: free end gaps in B
-      const double col_open = h1[r - 1] + (lastcol ? 0.0 : first_gap), col_extend = e1[r - 1] + (lastcol ? 0.0 : extend);
-      const double cs = col_open > col_extend ? col_open : col_extend;
-      double b = cs > rs ? cs : rs;
-      b = nogap > b ? nogap : b;
-      const double hv = valid ? (b < 0 ? 0.0 : b) : 0.0;
-      f[r] = valid ? rs : f[r]; en[r] = cs; hn[r] = hv;
-      // pairwise2.rint(x) = int(x * 1000 + 0.5); rint is monotone, so rint(max(x, y)) == max(rint(x), rint(y))
-      const int ro = (int)(row_open * 1000 + 0.5), re = (int)(row_extend * 1000 + 0.5);
-      const int co = (int)(col_open * 1000 + 0.5), ce = (int)(col_extend * 1000 + 0.5), ng = (int)(nogap * 1000 + 0.5);
-      const int rr = ro > re ? ro : re, cr = co > ce ? co : ce;
-      int br = rr > cr ? rr : cr; br = ng > br ? ng : br;
-      int t = ng == br ? 2 : 0;
-      t += rr == br ? (ro == rr ? 1 : 0) + (re == rr ? 8 : 0) : 0;
-      t += cr == br ? (co == cr ? 4 : 0) + (ce == cr ? 16 : 0) : 0;
-      sd[r] = hv; td[r] = valid ? t : -1;
-    }
-    // best score = max over the clipped cells (it starts at 0 in the reference too); kept out of the loop above: without fast-math
-    // the compare-select maximum is not a reduction the vectoriser accepts.  Rows without a cell on diagonal d hold 0, the border value.
+    alignas(64) double lane_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r0 = w_lo; r0 < w_hi; r0 += 8)
+      diag_group<MATRIX>(r0, r_lo, r_hi, r_lastcol, first_gap, extend, match, mismatch, h1, h2, hn, e1, en, f, ga, ea, ia, ibd, m0, m1, m2, m3, sd, td, lane_max);
+    // best score = max over the clipped cells (it starts at 0 in the reference too)
     double dm = 0;
-    for (int r = r_lo; r <= r_hi; ++r) dm = dm > sd[r] ? dm : sd[r];
+    for (int k = 0; k < 8; ++k) dm = dm > lane_max[k] ? dm : lane_max[k];
     diag_max[d] = dm;                                      // find_start only looks at diagonals that reach the best score
     local_max = local_max > dm ? local_max : dm;
   }
   return local_max;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static double fill_diagonals(bool matrix, int lenA, int lenB, int nl, double first_gap, double extend, double open2, const int* __restrict__ ia,
+                             const int* __restrict__ ibr, const double* __restrict__ mrow, int mstride, double match, double mismatch,
+                             double* __restrict__ work, double* __restrict__ score, int* __restrict__ trace, double* __restrict__ diag_max) {
+  return matrix ? fill_diagonals_body<true>(lenA, lenB, nl, first_gap, extend, open2, ia, ibr, mrow, mstride, match, mismatch, work, score, trace, diag_max)
+                : fill_diagonals_body<false>(lenA, lenB, nl, first_gap, extend, open2, ia, ibr, mrow, mstride, match, mismatch, work, score, trace, diag_max);
 }
 
 struct Start { double score; int row, col; };
@@ -140,7 +168,7 @@ struct Aligner {
   ScoreSet sc;
   std::vector<double> score;     // (lenA+1) x (lenB+1)
   std::vector<int> trace;        // -1 = None (border)
-  std::vector<double> dbuf, itab, dmax;  // per-diagonal work arrays of fill(); identity match table; best score of each diagonal
+  std::vector<double> dbuf, mrow, dmax;  // per-diagonal work arrays of fill(); identity match table; best score of each diagonal
   std::vector<int> tbuf, ia, ib;
   std::vector<Start> starts;
   double best = 0;
@@ -173,28 +201,22 @@ struct Aligner {
     ia.assign(NL, 0);
     ib.assign((size_t)lenB + 2 * NL + 2 * lenA + 16, 0);    // reversed letters of B with room for every row of every diagonal
     int* ibr = ib.data() + NL + lenA + 8;                   // index range used: 1 - lenA .. lenB - 2 + NL
-    double mtab[16];
-    int code[256]; for (int i = 0; i < 256; ++i) code[i] = -1;
-    int ncode = 0;
-    const double* tab = mtab; int stride = 4;
+    // letter codes.  Matrix scoring: 0..3, and mrow[k][r] = m[A[r-1]][k] for the sweep's selects.  Identity scoring on arbitrary
+    // letters: the byte itself (equal bytes match).  Rows without a cell on a diagonal are masked in the sweep, whatever their codes say
     if (sc.matrix) {
-      for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) mtab[i * 4 + k] = sc.m[i][k];
-      for (int i = 0; i < lenA; ++i) ia[i + 1] = base_index(A[i]);
+      mrow.assign((size_t)4 * ws, 0.0);
+      for (int i = 0; i < lenA; ++i) { const int a = base_index(A[i]); ia[i + 1] = a; for (int k = 0; k < 4; ++k) mrow[(size_t)k * ws + i + 1] = sc.m[a][k]; }
       for (int i = 0; i < lenB; ++i) ibr[lenB - 1 - i] = base_index(B[i]);
     } else {
-      // identity scoring on arbitrary letters: codes of first occurrence (at most 2 * overlap distinct letters) index a table with
-      // `match` on its diagonal
-      for (int i = 0; i < lenA; ++i) { const int ch = (unsigned char)A[i]; if (code[ch] < 0) code[ch] = ncode++; ia[i + 1] = code[ch]; }
-      for (int i = 0; i < lenB; ++i) { const int ch = (unsigned char)B[i]; if (code[ch] < 0) code[ch] = ncode++; ibr[lenB - 1 - i] = code[ch]; }
-      itab.assign((size_t)ncode * ncode, sc.mismatch);
-      for (int i = 0; i < ncode; ++i) itab[(size_t)i * ncode + i] = sc.match;
-      tab = itab.data(); stride = ncode;
+      for (int i = 0; i < lenA; ++i) ia[i + 1] = (unsigned char)A[i];
+      for (int i = 0; i < lenB; ++i) ibr[lenB - 1 - i] = (unsigned char)B[i];
     }
     for (int r = 1; r <= lenA; ++r) {
       f[r] = affine(r, 2 * open, extend);                 // row state before column 1
       ga[r] = r == lenA ? 0.0 : first_gap; ea[r] = r == lenA ? 0.0 : extend;
     }
-    best = fill_diagonals(lenA, lenB, NL, first_gap, extend, 2 * open, ia.data(), ibr, tab, stride, dbuf.data(), score.data(), trace.data(), dmax.data());
+    best = fill_diagonals(sc.matrix, lenA, lenB, NL, first_gap, extend, 2 * open, ia.data(), ibr, mrow.data(), ws, sc.match, sc.mismatch, dbuf.data(), score.data(),
+                          trace.data(), dmax.data());
   }
 
   void find_start(std::vector<Start>& st) {
