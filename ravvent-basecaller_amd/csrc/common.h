@@ -138,6 +138,12 @@ struct DecState {
   // value a key / a U' element can take (from the weights; |enc_out| <= 1) into [2^13, 2^14); descale = 2^-14 / scale (the query
   // and the alignments are scaled by 2^14)
   int mx_attention; float mx_kscale, mx_kdescale, mx_uscale, mx_udescale;
+  // ... and the cell product [ctx' | h] . Wcat2 too (mx_attention == 2): Wc16 = Wcat2 as MFMA B fragments of two f16 parts,
+  // [8 waves][32 (k-step, gate) pairs][2 parts][64 lanes][8 f16]; wave w owns units 16 w .. 16 w + 15 of all four gates; lane (n, kq)
+  // of pair p = 4 ks + g holds T . Wcat2[k][128 g + 16 w + n] / xs[k], k = 32 ks + 8 kq + 0..7, with xs = mx_uscale for the ctx' rows
+  // (k < 128) and 2^14 for the h rows -- the factors the inputs' f16 images carry -- and T the power of two that brings the largest
+  // such element into [2^13, 2^14); mx_cdescale = 1 / T
+  const uint16_t* Wc16; float mx_cdescale;
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

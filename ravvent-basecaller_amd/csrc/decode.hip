@@ -226,6 +226,7 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
 
 constexpr int WB = RV_MAX_BEAM;
 constexpr int ATT_THREADS = 512;
+#define RV_STAMP_W1(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 64 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 #define RV_STAMP(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 0 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -882,21 +883,31 @@ constexpr int PERSIST_MAX_NIT = 11;      // resident row groups of 32 steps: T_m
 // `part` also holds the matrix-pipe attention's alignment image (two f16 parts of [32 NIT steps][8 beam slots] = NIT * 256 floats):
 // with one beam that image is larger than the partial sums, so the block is sized for the larger of the two
 __host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PERSIST_MAX_NIT * 256 ? 4 * W * RV_G : PERSIST_MAX_NIT * 256; }
+// ATT == 3 (matrix-pipe cell product): gate pre-activations z~ [W][RV_G + 16] (one plane: the product is complete inside a wave; rows
+// padded so that the four beams a wave stores at once fall into different banks).  Weight cache in LDS: ALL 32 (k-step, gate) pairs
+// of wave 0 (64 KB) -- wave 0 takes the beam step first (5 k cycles) and would stream its share alone afterwards -- and the last
+// mxc_nc(W) pairs of each of the other seven waves (2 KB per pair and wave)
+__host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 2 : 1; }
+__host__ __device__ constexpr int mxc_cache_floats(int W) { return (32 + 7 * mxc_nc(W)) * 512; }
+constexpr int MXC_ZS = RV_G + 16;
+__host__ __device__ constexpr int part_floats_mxc(int W) { return W * MXC_ZS > PERSIST_MAX_NIT * 256 ? W * MXC_ZS : PERSIST_MAX_NIT * 256; }
 struct PersistLds {
-  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, wcache, total;
+  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, xim, wcache, total;
+  // ATT: 0 Luong on fp32 rows, 1 Bahdanau, 2 Luong on the matrix pipe, 3 = 2 + the cell product on the matrix pipe
   __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
+    const bool mxc = ATT == 3;
     int o = 0;
-    attT = o; o += RV_U * WB;          // attention vectors k-major beam-minor (cell input rows 0..127)
+    attT = o; if (!mxc) o += RV_U * WB;   // attention vectors k-major beam-minor (cell input rows 0..127); mxc: the f16 image `xim` instead
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
     qp = o; o += W * RV_U;             // h * log2(e): the score query
-    part = o; o += part_floats(W);     // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
+    part = o; o += mxc ? part_floats_mxc(W) : part_floats(W);     // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
                                        // layer's h-part partial sums [16][W][128] (after the gates -> merge)
     ctxp = part;                       // context partial sums of the 8 waves [8][W][128]: one cell -> inside `part` (idle between
     if (D > 1) { ctxp = o; o += 8 * W * RV_U; }   // the gates and the end of the step); two cells -> own space (`part` holds h . A_h then)
-    fold = o; o += 8 * 4 * 2 * 16 * 4; // wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
+    fold = o; o += mxc ? 1024 : 8 * 4 * 2 * 16 * 4;   // (mxc: only the query image, 2 parts x 1024 f16)   wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
                                        // second cell's recurrent partial sums [3][W][512] between the end of a step and its gates
-    hcT = o; o += RV_U * WB;           // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
+    hcT = o; if (!mxc) o += RV_U * WB;  // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
     att = o; o += W * RV_U;
     ml = o; o += 64 * WB;              // per-stream max [32][WB], per-stream sum [32][WB]
     mg = o; o += 2 * WB;               // merged max, 1/sum
@@ -908,12 +919,15 @@ struct PersistLds {
       b1s = o; o += RV_G;
     }
     pq = o; vat = o;
-    if (ATT) {                         // Bahdanau (basecaller.py:131-132): processed query (h . W_q) per beam, and attention_v
+    if (ATT == 1) {                    // Bahdanau (basecaller.py:131-132): processed query (h . W_q) per beam, and attention_v
       pq = o; o += W * RV_U;
       vat = o; o += RV_U;
     }
+    xim = o;
+    if (mxc) o += 2048;                // [ctx' | h] of the beams as MFMA A fragments: [2 parts][32 k-blocks][8 slots][8] f16
     wcache = o;
-    if (persist_weight_cache(W, D)) o += 24 * RV_G;   // 24 rows of the cell kernel kept in LDS (48 KB): the last 8 rows of K groups 1-3
+    if (mxc) o += mxc_cache_floats(W);
+    else if (persist_weight_cache(W, D)) o += 24 * RV_G;   // 24 rows of the cell kernel kept in LDS (48 KB): the last 8 rows of K groups 1-3
     total = o;
   }
 };
@@ -925,14 +939,18 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
                                                       const float* __restrict__ Nh /*D == 1: A_h . W_fc [128,V]*/) {
   constexpr int NT = 512;
   constexpr bool BAH = ATT == 1;           // Bahdanau scores on the VALU
-  constexpr bool MX = ATT == 2;            // Luong attention (scores and context) on the matrix pipe, split-f16 operands
+  constexpr bool MX = ATT >= 2;            // Luong attention (scores and context) on the matrix pipe, split-f16 operands
+  constexpr bool MXC = ATT == 3;           // ... and the cell product [ctx' | h] . Wcat2 (weights as B fragments from the Wc16 image)
+  constexpr int ZS = MXC ? MXC_ZS : RV_G;  // row stride of the gate pre-activations in `part`
+  constexpr int NC = mxc_nc(W);
   static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
-  static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= part_floats(W), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
+  static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= (ATT == 3 ? part_floats_mxc(W) : part_floats(W)), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
   static_assert(2 * 1024 * sizeof(_Float16) /* query image: 2 parts x [16 k-blocks][8 slots][8] f16 */ <= (8 * 4 * 2 * 16 * 4) * sizeof(float), "the query image must fit `fold`");
   extern __shared__ __align__(16) float dsm[];
-  const PersistLds L(W, D, BAH);
+  const PersistLds L(W, D, ATT);
+  _Float16* xim = reinterpret_cast<_Float16*>(dsm + L.xim);   // MXC only
   float* pqs = dsm + L.pq;  float* vat = dsm + L.vat;   // ATT == 1 only
-  constexpr bool CACHE = persist_weight_cache(W, D);
+  constexpr bool CACHE = MXC || persist_weight_cache(W, D);
   float* wcache = dsm + L.wcache;                        // CACHE only: rows 72 g + 104 + i of Wcat at [(8 g + i) * 512], g = 0..2
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* ctxp = dsm + L.ctxp;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
@@ -1015,10 +1033,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   // The cell's matrix-vector product of a step is taken on the PREVIOUS step's beams, before they are re-ordered (it only
   // needs their attention vector and h); the gate math then picks up the partial sums and the cell state of its parent
   // beam.  Zero initial state: partial sums 0, parents = identity.
-  for (int i = tid; i < RV_U * WB; i += NT) attT[i] = 0.f;
-  for (int i = tid; i < RV_U * WB; i += NT) hcT[i] = 0.f;
+  if (!MXC) {
+    for (int i = tid; i < RV_U * WB; i += NT) attT[i] = 0.f;
+    for (int i = tid; i < RV_U * WB; i += NT) hcT[i] = 0.f;
+  }
   for (int i = tid; i < 2 * W * RV_U; i += NT) cS[i] = 0.f;
-  for (int i = tid; i < 4 * W * RV_G; i += NT) part[i] = 0.f;
+  for (int i = tid; i < (MXC ? W * ZS : 4 * W * RV_G); i += NT) part[i] = 0.f;
+  if (MXC) for (int i = tid; i < 2048; i += NT) dsm[L.xim + i] = 0.f;
   if (D > 1) {
     for (int i = tid; i < RV_U * WB; i += NT) h0T[i] = 0.f;
     for (int i = tid; i < 2 * W * RV_U; i += NT) cS1[i] = 0.f;
@@ -1028,7 +1049,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[(i % V) * FCW + i / V] = d.W_fc[i];
   if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[(i % V) * FCW + i / V] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
   if (tid < V) s_wfc[RV_MAX_VOCAB * FCW + tid] = d.b_fc[tid];
-  if (CACHE) {
+  if (MXC) {   // wave 0's 32 pairs, then the last NC pairs of waves 1-7: 2 KB each, in image order
+    const uint4* src = reinterpret_cast<const uint4*>(d.Wc16);
+    uint4* dst = reinterpret_cast<uint4*>(wcache);
+    for (int i = tid; i < 32 * 128; i += NT) dst[i] = src[i];
+    for (int i = tid; i < 7 * NC * 128; i += NT) dst[32 * 128 + i] = src[(size_t)((1 + i / (NC * 128)) * 32 + 32 - NC) * 128 + i % (NC * 128)];
+  } else if (CACHE) {
     for (int i = tid; i < 24 * (RV_G / 4); i += NT) {
       const int r = i >> 7, c = i & 127;
       *reinterpret_cast<float4*>(&wcache[r * RV_G + 4 * c]) =
@@ -1079,13 +1105,22 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int col = g * RV_U + u;
-        z4[g] = (((part[(0 * W + pb) * RV_G + col] + part[(1 * W + pb) * RV_G + col]) + part[(2 * W + pb) * RV_G + col]) +
-                 part[(3 * W + pb) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
+        if constexpr (MXC)
+          z4[g] = part[pb * ZS + col] + zb[s_tok[w] * RV_G + col];
+        else
+          z4[g] = (((part[(0 * W + pb) * RV_G + col] + part[(1 * W + pb) * RV_G + col]) + part[(2 * W + pb) * RV_G + col]) +
+                   part[(3 * W + pb) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
       }
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
-      if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
+      if (D > 1) h0T[u * WB + w] = hh; else { if (!MXC) hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
+      if constexpr (MXC) {     // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
+        const float sv = hh * 16384.f;
+        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+        _Float16* xq = xim + (((RV_U + u) >> 3) * 8 + w) * 8 + (u & 7);
+        xq[0] = hi; xq[2048] = lo;
+      }
       if constexpr (MX) {      // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
         const float sv = (hh * LOG2E) * 16384.f;
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
@@ -1305,7 +1340,15 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         const int col = 16 * wv + l16;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-          if (kq + 4 * i < W) { const float av = acc[i] * d.mx_udescale; att[(kq + 4 * i) * RV_U + col] = av; attT[col * WB + kq + 4 * i] = av; }
+          if (kq + 4 * i < W) {
+            const float av = acc[i] * d.mx_udescale; att[(kq + 4 * i) * RV_U + col] = av;
+            if constexpr (MXC) {   // ctx' as A fragments of the cell product: k = col, ctx' . mx_uscale (= acc 2^-14, below 2^14) in two f16 parts
+              const float sv = acc[i] * (1.0f / 16384.f);
+              const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+              _Float16* xq = xim + ((col >> 3) * 8 + kq + 4 * i) * 8 + (col & 7);
+              xq[0] = hi; xq[2048] = lo;
+            } else attT[col * WB + kq + 4 * i] = av;
+          }
       }
       __syncthreads();
     } else {
@@ -1470,13 +1513,18 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         if (cand) { val = lg[v]; d.step_logits[((size_t)step * d.B + b) * V + v] = val; }
       } else if (cand) {
         if (d.step_logits) d.step_logits[(((size_t)step * d.B + b) * W + w) * V + v] = lg[w * RV_MAX_VOCAB + v];   // debug tap (option persist_taps)
-        float m = lg[w * RV_MAX_VOCAB];
-        for (int x = 1; x < V; ++x) m = fmaxf(m, lg[w * RV_MAX_VOCAB + x]);
-        float ssum = 0.f;
-        for (int x = 0; x < V; ++x) ssum += __expf(lg[w * RV_MAX_VOCAB + x] - m);
+        float lv[RV_MAX_VOCAB];                             // the beam's logits in two LDS reads; same order of operations as the loops
+        *reinterpret_cast<float4*>(lv) = *reinterpret_cast<const float4*>(&lg[w * RV_MAX_VOCAB]);
+        *reinterpret_cast<float4*>(lv + 4) = *reinterpret_cast<const float4*>(&lg[w * RV_MAX_VOCAB + 4]);
+        float m = lv[0];
+#pragma unroll
+        for (int x = 1; x < RV_MAX_VOCAB; ++x) m = x < V ? fmaxf(m, lv[x]) : m;
+        float ssum = 0.f, mine = lv[0];
+#pragma unroll
+        for (int x = 0; x < RV_MAX_VOCAB; ++x) { ssum += x < V ? __expf(lv[x] - m) : 0.f; mine = x == v ? lv[x] : mine; }
         const float lse = __logf(ssum);
         const bool fin = s_fin[w] != 0;
-        const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (lg[w * RV_MAX_VOCAB + v] - m) - lse;
+        const float lp = fin ? (v == d.end_token ? 0.f : -FLT_MAX) : (mine - m) - lse;
         val = s_lprob[w] + lp;
       }
       bool taken = !cand;
@@ -1524,10 +1572,66 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       if (lane == 0) s_allfin = __popcll(fmask) == W;
       }
+      RV_STAMP(d, step, 11);      // end of the beam step (wave 0)
     }
     // ================= next step's cell product on THIS step's beams: z~[w] = [attention_w | h_w] . Wcat (the beam step above
     //   only decides which z~ each new beam inherits).  thread = (4 gate columns c4, K group kg); waves 1-7 start at once,
     //   wave 0 joins after the beam step, so K group 0 (waves 0-1) is the short one: rows 0-39 | 40-111 | 112-183 | 184-255.
+    if constexpr (MXC) {
+      // Matrix pipe: z~ [beams x 512] = x [beams x 256] . Wcat2 as split-f16 MFMAs.  Wave wv owns units 16 wv .. 16 wv + 15 of all
+      // four gates over the whole K (no partial sums to merge): 32 (k-step, gate) pairs, each one B fragment pair (high, low
+      // part; 2 KB per wave) streamed from the Wc16 image through a rolling window of NB pairs, the last NC pairs from LDS.  A = the
+      // beams' [ctx' | h] image (rows = beam slots as in the scores), three exact part products per pair.
+      if (step + 1 < steps) {
+        RV_STAMP_W1(d, step, 12);
+        const int l16 = lane & 15, kq = lane >> 4;
+        const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;
+        const uint4* wimg = reinterpret_cast<const uint4*>(d.Wc16) + (size_t)wv * (32 * 128) + lane;   // pair p, part q: [(2 p + q) * 64]
+        const _Float16* xa = xim + (kq * 8 + aslot) * 8;     // k-step ks: + 256 ks; low part: + 2048
+        constexpr int NS = 32 - NC, NB = 4;
+        f4v acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+        auto mm = [&](int p, const uint4& vh, const uint4& vl) {
+          const int ks = p >> 2, g = p & 3;
+          const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
+          const h8 wh = __builtin_bit_cast(h8, vh), wl = __builtin_bit_cast(h8, vl);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[g], 0, 0, 0);
+        };
+        if (wv == 0) {                                       // after the beam step: everything from LDS
+          const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;
+#pragma unroll
+          for (int p = 0; p < 32; ++p) mm(p, wc[(2 * p) * 64], wc[(2 * p + 1) * 64]);
+        } else {
+          uint4 bh[NB], bl[NB];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) { bh[i] = wimg[(2 * i) * 64]; bl[i] = wimg[(2 * i + 1) * 64]; }
+          {                                                  // the on-chip pairs first: the first requests are in flight meanwhile
+            const uint4* wc = reinterpret_cast<const uint4*>(wcache) + 32 * 128 + (size_t)(wv - 1) * (NC * 128) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mm(32 - NC + c, wc[(2 * c) * 64], wc[(2 * c + 1) * 64]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) {
+            mm(p, bh[p % NB], bl[p % NB]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + NB < NS) { bh[p % NB] = wimg[(2 * (p + NB)) * 64]; bl[p % NB] = wimg[(2 * (p + NB) + 1) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // C/D: lane (column l16, kq) holds rows 4 kq + i = beams kq + 4 i
+        constexpr int NI = W > 4 ? 2 : 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            if (kq + 4 * i < W) part[(kq + 4 * i) * ZS + RV_U * g + 16 * wv + l16] = acc[g][i] * d.mx_cdescale;
+        RV_STAMP_W1(d, step, 13);
+      }
+    } else
     if (step + 1 < steps) {
       const int c4 = tid & 127, kg = tid >> 7;
       // one cell: rows 0-39 | 40-111 | 112-183 | 184-255;  two cells: 64 rows each here, and K groups 1-3 also take the
@@ -1700,7 +1804,7 @@ __global__ __launch_bounds__(64) void k_dec_reduce_steps(DecParts p) {
 template <int W, int D, int ATT>
 static void launch_persist_wd(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                               const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
-  const size_t shm = sizeof(float) * PersistLds(W, D, ATT == 1).total;
+  const size_t shm = sizeof(float) * PersistLds(W, D, ATT).total;
   if (d.Tm <= 64) hipLaunchKernelGGL((k_dec_persist<W, 2, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
   else if (d.Tm <= 256) hipLaunchKernelGGL((k_dec_persist<W, 8, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
   else hipLaunchKernelGGL((k_dec_persist<W, 11, D, ATT>), dim3(d.B), dim3(512), shm, s, d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh);
@@ -1712,11 +1816,12 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
     if (d.depth > 1) { launch_persist_wd<W, 2, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
   if (d.attention == 1) launch_persist_wd<W, 1, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);     // Bahdanau: one decoder cell
+  else if (d.mx_attention == 2) launch_persist_wd<W, 1, 3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);  // Luong, attention and cell product on the matrix pipe
   else if (d.mx_attention) launch_persist_wd<W, 1, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);  // Luong, scores and context on the matrix pipe
   else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, d.attention == 1).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
+  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, d.attention == 1 ? 1 : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0)).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
   return (d.attention == 0 || (d.attention == 1 && d.depth == 1)) && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
@@ -1811,6 +1916,9 @@ static hipError_t configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
   if constexpr (W <= 5) {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);

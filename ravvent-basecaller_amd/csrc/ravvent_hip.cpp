@@ -63,6 +63,8 @@ struct RvContext {
   uint16_t* d_Wh = nullptr;                 // derived: ... as two f16 parts of the column-scaled kernels + 512 column factors, [enc][layer-1][dir][RV_WH_SLOT]
   int opt_split_proj = 2;                   // fused projection on split-bf16 MFMAs (six part products, f32-equivalent); 0 = f32 MFMAs
   int opt_mx_att = 1;                       // persistent decode (Luong, one cell): attention on the matrix pipe
+  int opt_mx_cell = 1;                      // ... and its cell product [ctx' | h] . Wcat2 as well (needs opt_mx_att)
+  float mx_cdescale = 1.f;                  // 1 / the power-of-two scale of the Wc16 image (set by rv_load_weights)
   float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
   uint16_t* d_Ua = nullptr;                 // derived: recurrent kernels as MFMA A fragments (two f16 parts) + row factors, [enc][layer][dir][RV_UA_SLOT]
   uint16_t* d_Wx16 = nullptr;               // derived: input kernels of encoder layers >= 1, both directions, as the split GEMM's B slabs, [enc][layer-1][RV_WX16_SLOT]
@@ -76,6 +78,7 @@ struct RvContext {
   float* d_Wmp = nullptr;                   // derived: [W_mem | A_c] [256][256] (A_c = W_att rows 128..383): projection of the attention memory for the persistent decode
   float* d_Wcat2 = nullptr;                 // derived (one decoder cell): [W_a ; U + A_h W_a] [256][512]
   float* d_Nh = nullptr;                    // derived (one decoder cell): A_h W_fc [128][V]
+  uint16_t* d_Wc16 = nullptr;               // derived (one decoder cell): Wcat2 as two f16 parts in MFMA B-fragment order (DecState::Wc16)
   uint16_t* d_Wmp16 = nullptr;              // derived: Wmp as two f16 parts in MFMA fragment order + column factors (launch_gemm_mem_split)
   float* mem2 = nullptr;                    // [B,Tm,256] = enc_out . Wmp: keys | attention-layer image of the values
   float* d_WcatT = nullptr;                 // derived: ([W_dec[V:] ; U_dec])^T, [512][256]
@@ -523,6 +526,8 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   // keep sampling after their end token, so greedy decodes as one piece).
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
   d.chunk_steps = nullptr;
+  d.mx_attention = (h->opt_mx_att && c.attention == RV_ATT_LUONG && d.depth == 1) ? (h->opt_mx_cell ? 2 : 1) : 0;   // (sizes the decode's LDS)
+  d.Wc16 = h->d_Wc16; d.mx_cdescale = h->mx_cdescale;
   h->lpersist = (persist_ok && dec_persist_supported(d)) ? 1 : 0;
   if (persist_ok && !h->lpersist) return fail(h, RV_ESTATE, "internal: persistent decode predicate mismatch");
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
@@ -579,7 +584,6 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
       else launch_gemm_f32(g, false, s);
     }
     d.values = h->mem2; part[0].values = h->mem2;
-    d.mx_attention = (h->opt_mx_att && c.attention == RV_ATT_LUONG && d.depth == 1) ? 1 : 0;
     d.mx_kscale = h->mx_kscale; d.mx_kdescale = std::ldexp(1.0f, -14) / h->mx_kscale;
     d.mx_uscale = h->mx_uscale; d.mx_udescale = std::ldexp(1.0f, -14) / h->mx_uscale;
     Scope sc(h, "dec_persist", nullptr, true);
@@ -759,7 +763,7 @@ int create_child(RvContext* p, RvContext** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(p, RV_EHIP, "hipStreamCreate failed for an asynchronous context"); }
   h->d_w = p->d_w; h->n_w = p->n_w;
   h->d_WmemT = p->d_WmemT; h->d_Up = p->d_Up; h->d_Wp = p->d_Wp; h->d_Wsb = p->d_Wsb; h->d_Wh = p->d_Wh; h->d_Ua = p->d_Ua;
-  h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16;
+  h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16; h->d_Wc16 = p->d_Wc16;
   h->d_WcatT = p->d_WcatT;
   bind_weights(h);
   const int rc = alloc_slab_buffers(h);
@@ -772,7 +776,7 @@ int create_child(RvContext* p, RvContext** out) {
 void sync_child(RvContext* k, const RvContext* p) {
   k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
   k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
-  k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_tail_wave = p->opt_tail_wave;
+  k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->opt_tail_wave = p->opt_tail_wave;
   k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
   k->opt_taps = 0; k->opt_ptaps = 0;      // debug taps belong to the synchronous calls
   k->inflight_hint = p->inflight_hint;
@@ -831,6 +835,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
   TRY(dalloc(h, &h->d_Wmp16, RV_WMP16_SLOT));
+  TRY(dalloc(h, &h->d_Wc16, (size_t)2 * RV_E * RV_G));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
@@ -1090,6 +1095,31 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
         }
       HIPCHK(h, hipMemcpy(h->d_Wcat2, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));
       HIPCHK(h, hipMemcpy(h->d_Nh, nh.data(), nh.size() * sizeof(float), hipMemcpyHostToDevice));
+      {   // the same kernel for the matrix-pipe cell product (DecState::Wc16): rows divided by the factor their input's f16 image
+          // carries (exact: powers of two), one power-of-two scale for the tensor, two f16 parts in B-fragment order per wave
+        auto xs = [&](int k) { return k < RV_U ? h->mx_uscale : 16384.f; };
+        float mx = 0.f;
+        for (int k = 0; k < RV_E; ++k)
+          for (int n = 0; n < RV_G; ++n) mx = std::max(mx, std::fabs(w2[(size_t)k * RV_G + n] / xs(k)));
+        int ex = 0;
+        if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);
+        const float T = std::ldexp(1.0f, 14 - ex);
+        h->mx_cdescale = 1.0f / T;
+        std::vector<uint16_t> img((size_t)2 * RV_E * RV_G);
+        for (int wv = 0; wv < 8; ++wv)
+          for (int pr = 0; pr < 32; ++pr)
+            for (int ln = 0; ln < 64; ++ln)
+              for (int j = 0; j < 8; ++j) {
+                const int ks = pr >> 2, g = pr & 3, k = 32 * ks + 8 * (ln >> 4) + j, n = RV_U * g + 16 * wv + (ln & 15);
+                const float v = (w2[(size_t)k * RV_G + n] / xs(k)) * T;
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                img[(((((size_t)wv * 32 + pr) * 2 + 0) * 64) + ln) * 8 + j] = hb;
+                img[(((((size_t)wv * 32 + pr) * 2 + 1) * 64) + ln) * 8 + j] = lb;
+              }
+        HIPCHK(h, hipMemcpy(h->d_Wc16, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
     }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
     std::vector<float> m((size_t)RV_U * RV_E);
@@ -1204,6 +1234,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
     h->opt_async_depth = value;
   }
   else if (!strcmp(key, "matrix_attention")) h->opt_mx_att = value != 0;
+  else if (!strcmp(key, "matrix_cell")) h->opt_mx_cell = value != 0;
   else if (!strcmp(key, "split_projection")) h->opt_split_proj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(key, "attend_threads")) {
     if (value != 0 && value != 256 && value != 512) return fail(h, RV_EINVAL, "attend_threads must be 0, 256 or 512");
