@@ -1600,10 +1600,23 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[g], 0, 0, 0);
         };
-        if (wv == 0) {                                       // after the beam step: everything from LDS
-          const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;
+        if (wv == 0) {                                       // after the beam step: everything from LDS, one k-step (four gates) at a
+          const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;   // time with the four accumulators taking turns (the waves that
+#pragma unroll                                                               // stream do not care: 87 cycles per MFMA at the link's rate)
+          for (int ks = 0; ks < 8; ++ks) {
+            const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
+            h8 wh[4], wl[4];
 #pragma unroll
-          for (int p = 0; p < 32; ++p) mm(p, wc[(2 * p) * 64], wc[(2 * p + 1) * 64]);
+            for (int g = 0; g < 4; ++g) {
+              wh[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g)) * 64]); wl[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g) + 1) * 64]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g], acc[g], 0, 0, 0);
+          }
         } else {
           uint4 bh[NB], bl[NB];
 #pragma unroll
