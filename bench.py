@@ -223,6 +223,8 @@ def main():
                     help="library option wide_recurrence: mx = matrix-pipe recurrence, 16 chunks per workgroup (library default); "
                          "fma = packed-FMA kernels; auto = per call by chunks in flight")
     ap.add_argument("--depth", type=int, default=10, help="slabs in flight through the asynchronous calls (1..16); 0 = the synchronous call")
+    ap.add_argument("--gather-per-step", action="store_true", help="N > 1: one all-gather per step (dist.sharded_beam_search_stream) instead of "
+                    "ONE at the end of the steps (dist.sharded_beam_search_many, the default)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a fixed read of --read-chunks chunks per step, sharded over the GPUs")
     ap.add_argument("--read-chunks", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -287,7 +289,11 @@ def main():
         decode -> ONE all-gather (RCCL over xGMI) per step, the next step's shard submitted before this one is gathered."""
         out, stamps = None, []
         if world > 1:
-            if depth:
+            if depth and not args.gather_per_step:     # every rank streams its shards of all k steps, ONE all-gather at the end
+                outs = rv.dist.sharded_beam_search_many(bc, [(d_raw, d_ev)] * k, W, L, slab=B)
+                out = outs[-1]
+                stamps = [time.perf_counter()] * k
+            elif depth:
                 for out in rv.dist.sharded_beam_search_stream(bc, ((d_raw, d_ev) for _ in range(k)), W, L, slab=B):
                     stamps.append(time.perf_counter())
             else:
@@ -503,7 +509,8 @@ def main():
                                       if depth else "synchronous calls, one slab at a time"),
                        "recurrence": ("matrix pipe, 16 chunks per workgroup (k_lstm_rec_mx + split-f16 projection GEMM)" if wide_used
                                       else "packed fp32 FMAs (k_lstm_rec_tw / k_lstm_rec_proj)"),
-                       "parallelism": f"chunk-shard x{world}" + (" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if world > 1 else "")},
+                       "parallelism": f"chunk-shard x{world}" + ((" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if (args.gather_per_step or not depth) else
+                                                                       " + ONE RCCL all-gather at the end of the steps (dist.sharded_beam_search_many)") if world > 1 else "")},
             "roofline": roof,
             "roofline_isolated": roof_iso,
             "roofline_top2": top2,

@@ -187,6 +187,69 @@ def sharded_beam_search_stream(basecaller, slabs, beam_width: int, max_output_le
         yield finish(queue.pop(0))
 
 
+def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len: int, group=None, slab: int | None = None):
+    """A whole queue of FULL slabs (raw, event) with ONE collective at the end (north_star: "read-chunks shard across the GPUs with a
+    single RCCL gather at the end"): every rank streams its shards of all the slabs through the asynchronous calls, packs them into one
+    int32 tensor [K, n_max, 2 (L-1) + 1] (the wire rows of `gather_calls`; n_max = the largest shard of any slab) and one
+    `all_gather_into_tensor` returns everything; no host synchronisation with the other ranks before that.  Returns a list of
+    (tokens [n_k, S_k], scores [n_k, S_k]) in slab order, each identical to `sharded_beam_search` of that slab."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    slabs = list(slabs)
+    steps = max(int(max_output_len) - 1, 0)
+    end_token = int(basecaller.output_end_token)
+    mode = basecaller.input_data_type
+    ns = [(raw if raw is not None else event).shape[0] for raw, event in slabs]
+    K = len(slabs)
+    if K == 0:
+        return []
+    n_max = max(max(-(-n // world) for n in ns), 1)
+    cols = 2 * steps + 1
+    limit = int(slab) if slab else None
+
+    def shards():          # this rank's pieces of every slab, in order; a shard larger than `slab` is cut into several calls
+        for (raw, event), n in zip(slabs, ns):
+            lo, hi = shard_range(n, rank, world)
+            step = limit if limit else max(hi - lo, 1)
+            for a in range(lo, hi, step):
+                b = min(a + step, hi)
+                pick = lambda x: None if x is None else x[a:b]
+                yield {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
+    pieces = [len(range(*shard_range(n, rank, world), limit if limit else max(n, 1))) for n in ns]
+    if hasattr(basecaller, "beam_search_stream"):
+        results = iter(basecaller.beam_search_stream(shards(), beam_width, max_output_len))
+    else:
+        results = (basecaller.beam_search_prediction(x, beam_width=beam_width, max_output_len=max_output_len) for x in shards())
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device(getattr(basecaller, "device", None) or torch.device("cuda", torch.cuda.current_device())) if nccl else torch.device("cpu")
+    packed = torch.empty((K, n_max, cols), dtype=torch.int32, device=dev)
+    packed[:, :, :steps] = end_token
+    packed[:, :, steps:] = 0
+    for k in range(K):
+        row, s_k = 0, 0
+        for _ in range(pieces[k]):
+            tok, sc = next(results)
+            n_loc, s_loc = tok.shape
+            if n_loc and s_loc:
+                scv = sc.to(dev, torch.float32).contiguous()
+                packed[k, row:row + n_loc, :s_loc] = tok.to(dev, torch.int32)
+                packed[k, row:row + n_loc, steps:steps + s_loc] = scv.view(torch.int32)
+                if s_loc < steps:      # a piece that stopped early: unchanged top-1 score on the steps a longer slab-wide loop still runs
+                    packed[k, row:row + n_loc, steps + s_loc:2 * steps] = scv[:, s_loc - 1:s_loc].view(torch.int32)
+            row += n_loc
+            s_k = max(s_k, s_loc)
+        packed[k, :, 2 * steps] = s_k
+    for _ in results:      # (nothing left: the generator collects its tickets)
+        pass
+    gathered = torch.empty((world, K, n_max, cols), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered.view(world * K, n_max, cols), packed, group=group)
+    S = gathered[:, :, 0, 2 * steps].max(dim=0).values.tolist()          # per slab: the slab-wide loop runs to the longest shard
+    out = []
+    for k, n in enumerate(ns):
+        rows = gathered[:, k].reshape(world * n_max, cols)[_read_order_index(n, world, n_max, dev)]
+        out.append((rows[:, :S[k]].clone(), rows[:, steps:steps + S[k]].clone().view(torch.float32)))
+    return out
+
+
 def pack_call_arrays(bases, probs, lens, n_total: int, max_steps: int, world: int):
     """This rank's rows of the read-level wire format, one int32 row per chunk, padded to the common shard size
     n_max = ceil(n_total / world): [prob bits (L-1) | base bytes, 4 per word | length]."""

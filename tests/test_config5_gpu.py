@@ -93,6 +93,10 @@ def _read_rank(rank, world, port, backend, q):
     out["host"] = (t.cpu().numpy(), s.cpu().numpy(), str(t.device))
     t, s = rv.dist.sharded_beam_search(bc, torch.from_numpy(raw[:n]).cuda(), torch.from_numpy(ev[:n]).cuda(), 5, L, slab=256)
     out["dev"] = (t.cpu().numpy(), s.cpu().numpy(), str(t.device))
+    # a queue of slabs with ONE collective at the end (what bench.py --gpus N times): the first of three slabs is the one above
+    d_raw, d_ev = torch.from_numpy(raw[:n]).cuda(), torch.from_numpy(ev[:n]).cuda()
+    many = rv.dist.sharded_beam_search_many(bc, [(d_raw, d_ev), (d_raw[:300], d_ev[:300]), (d_raw[5:6], d_ev[5:6])], 5, L, slab=256)
+    out["many"] = [(t.cpu().numpy(), s.cpu().numpy(), str(t.device)) for t, s in many]
     if rank == 0:
         q.put(out)
     dist.barrier()
@@ -134,6 +138,21 @@ def _single_process_reference(rv):
     return single["merged_seq"], t.numpy(), s.numpy()
 
 
+def _check_many(rv, out, t, s):
+    """dist.sharded_beam_search_many (one gather for three slabs) against single-process decodes of the same slabs."""
+    sig, lab, raw, ev, nuc = _long_read(rv)
+    L = nuc.shape[1]
+    bc = _read_basecaller(rv, L)
+    refs = [(t, s)]
+    for sl in (slice(0, 300), slice(5, 6)):
+        tt, ss = bc.beam_search_prediction((raw[:700][sl], ev[:700][sl]), 5, L)
+        refs.append((tt.numpy(), ss.numpy()))
+    bc.close()
+    assert len(out["many"]) == 3
+    for (mt, ms, _), (rt, rs) in zip(out["many"], refs):
+        assert mt.shape == rt.shape and (mt == rt).all() and np.array_equal(ms, rs)
+
+
 def test_config5_long_read_two_real_ranks(rv):
     """The shipped multi-GPU path on the 50 k-base read with two real ranks that share this box's GPU (gloo: RCCL refuses two
     ranks on one device): run_read_sharded -> one all-gather -> merger on rank 0 == the single-process read."""
@@ -144,6 +163,7 @@ def test_config5_long_read_two_real_ranks(rv):
     for key in ("host", "dev"):
         bad = np.nonzero((out[key][0] != t).any(axis=1) | (out[key][1] != s).any(axis=1))[0] if out[key][0].shape == t.shape else None
         assert out[key][0].shape == t.shape and bad.size == 0, (key, out[key][0].shape, t.shape, None if bad is None else (bad.size, bad[:12]))
+    _check_many(rv, out, t, s)
 
 
 def test_rccl_gather_world_one(rv):
@@ -157,6 +177,8 @@ def test_rccl_gather_world_one(rv):
     for key in ("host", "dev"):
         assert out[key][2].startswith("cuda"), out[key][2]           # the gathered result lives where RCCL put it
         assert out[key][0].shape == t.shape and (out[key][0] == t).all() and np.array_equal(out[key][1], s), key
+    assert all(m[2].startswith("cuda") for m in out["many"])
+    _check_many(rv, out, t, s)
 
 
 @pytest.mark.parametrize("enc_depth,dec_depth,attention", [(2, 1, "luong"), (3, 2, "luong"), (2, 1, "bahdanau")])

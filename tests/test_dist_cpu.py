@@ -188,3 +188,45 @@ def test_sharded_stream_equals_single(rv):
         raw, ev, _ = rv.synthetic.make_slab(n, 24, 6, seed=20 + n)
         rtok, rsc = cpu_port.run(cfg.oracle_cfg(), 2, 7, blob, raw, ev, 3, 9)
         assert tok.shape == rtok.shape and (tok == rtok).all() and np.array_equal(sc, rsc), n
+
+
+def _many_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravvent_basecaller_amd as rv
+    cfg = rv.RvConfig()
+    flat = rv.weights.init_weights(cfg, seed=4)
+    flat["b_fc"][1] = 1.5
+    eng = _OracleEngine(cfg, rv.weights.pack(cfg, flat))
+    slabs = [rv.synthetic.make_slab(n, 24, 6, seed=20 + n)[:2] for n in (5, 1, 8, 4, 7)]      # n = 1: rank 1's shard is empty
+    outs = rv.dist.sharded_beam_search_many(eng, slabs, beam_width=3, max_output_len=9, slab=3)   # (8 chunks: shard of 4 > slab 3)
+    if rank == 0:
+        q.put([(t.numpy(), s.numpy()) for t, s in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_many_one_gather_equals_single(rv):
+    """dist.sharded_beam_search_many: every rank decodes its shards of ALL the slabs, ONE all-gather at the end; per slab identical to
+    the single-process decode -- with an empty shard, ragged slab sizes and a shard larger than the slab limit."""
+    from oracle import cpu_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 777) % 2000
+    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = rv.RvConfig()
+    flat = rv.weights.init_weights(cfg, seed=4)
+    flat["b_fc"][1] = 1.5
+    blob = rv.weights.pack(cfg, flat)
+    assert len(outs) == 5
+    for (tok, sc), n in zip(outs, (5, 1, 8, 4, 7)):
+        raw, ev, _ = rv.synthetic.make_slab(n, 24, 6, seed=20 + n)
+        rtok, rsc = cpu_port.run(cfg.oracle_cfg(), 2, 7, blob, raw, ev, 3, 9)
+        assert tok.shape == rtok.shape and (tok == rtok).all() and np.array_equal(sc, rsc), n
