@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10, help="slabs in flight through the asynchronous calls (1..16); 0 = the synchronous call")
     ap.add_argument("--gather-per-step", action="store_true", help="N > 1: one all-gather per step (dist.sharded_beam_search_stream) instead of "
                     "ONE at the end of the steps (dist.sharded_beam_search_many, the default)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: with --gpus 1, run the N > 1 code path in a one-rank process group")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a fixed read of --read-chunks chunks per step, sharded over the GPUs")
     ap.add_argument("--read-chunks", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,7 +255,11 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dist_path = world > 1 or args.force_dist      # --force-dist: the N > 1 code path (process group, shard -> decode -> gather) with ONE rank
+    if dist_path:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -281,16 +286,16 @@ def main():
     if depth:
         bc.set_async_depth(depth)
     bc.set_option("wide_recurrence", {"mx": 1, "fma": 0, "auto": -1}[args.recurrence])
-    slabs_of_step = [(d_raw[a:a + B], d_ev[a:a + B]) for a in range(lo, hi, B)] if world == 1 else None
+    slabs_of_step = [(d_raw[a:a + B], d_ev[a:a + B]) for a in range(lo, hi, B)] if (not dist_path or os.environ.get("RV_BENCH_PLAIN_STEPS")) else None
 
     def run_steps(k):
         """k steps; returns (last result, per-step completion times).  depth > 0: the steps' slabs stream through the asynchronous
         calls, `depth` in flight; a step is complete when its last slab is collected.  N > 1: the shipped multi-GPU path, shard ->
         decode -> ONE all-gather (RCCL over xGMI) per step, the next step's shard submitted before this one is gathered."""
         out, stamps = None, []
-        if world > 1:
+        if dist_path and not os.environ.get("RV_BENCH_PLAIN_STEPS"):     # (diagnostic switch: process group up, steps without it)
             if depth and not args.gather_per_step:     # every rank streams its shards of all k steps, ONE all-gather at the end
-                outs = rv.dist.sharded_beam_search_many(bc, [(d_raw, d_ev)] * k, W, L, slab=B)
+                outs = rv.dist.sharded_beam_search_many(bc, [(d_raw, d_ev)] * k, W, L, slab=B, reuse_buffers=True)
                 out = outs[-1]
                 stamps = [time.perf_counter()] * k
             elif depth:
@@ -315,7 +320,7 @@ def main():
         return out, stamps
 
     def fence():
-        if world > 1:
+        if dist_path:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,13 +329,24 @@ def main():
     bc.set_option("profile", 3)
     import gc
     gc.collect(); gc.disable()             # before the warm-up: a collection between warm-up and timing idles the GPU (~50 ms)
+    if dist_path and depth and not args.gather_per_step:   # the gather buffers of the K timed steps, sized ahead of time (a first-use
+        rv.dist.reserve_many_buffers(bc, args.steps, n_global, L)   # allocation inside the timed region costs more than the collective)
+    if dist_path:                          # the FIRST barrier of a process group sets its collective up (tens of ms with RCCL): not between
+        dist.barrier()                     # the warm-up and the timed region, where the idle GPU would drop its clocks (see --help of RV_BENCH_GAP_MS)
     run_steps(max(args.warmup, 1))         # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
+    for _ in range(int(os.environ.get("RV_BENCH_PRERUN", "0"))):      # diagnostic: whole untimed passes of the K steps first
+        run_steps(args.steps)
     bc.reset_profile()
     fence()
+    if os.environ.get("RV_BENCH_GAP_MS"):          # diagnostic: an idle gap between the warm-up and the timed region
+        time.sleep(float(os.environ["RV_BENCH_GAP_MS"]) * 1e-3)
     t0 = time.perf_counter()
     (tok, sc), stamps = run_steps(args.steps)
+    t_run = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("RV_BENCH_VERBOSE"):
+        print(f"timed region: run_steps {t_run * 1e3:.3f} ms, closing fence {(dt - t_run) * 1e3:.3f} ms", file=sys.stderr)
     gc.enable()
     per_step = [b - a for a, b in zip([t0] + stamps[:-1], stamps)]
     if world > 1:
@@ -510,7 +526,7 @@ def main():
                        "recurrence": ("matrix pipe, 16 chunks per workgroup (k_lstm_rec_mx + split-f16 projection GEMM)" if wide_used
                                       else "packed fp32 FMAs (k_lstm_rec_tw / k_lstm_rec_proj)"),
                        "parallelism": f"chunk-shard x{world}" + ((" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if (args.gather_per_step or not depth) else
-                                                                       " + ONE RCCL all-gather at the end of the steps (dist.sharded_beam_search_many)") if world > 1 else "")},
+                                                                       " + ONE RCCL all-gather at the end of the steps (dist.sharded_beam_search_many)") if dist_path else "")},
             "roofline": roof,
             "roofline_isolated": roof_iso,
             "roofline_top2": top2,
@@ -542,7 +558,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rv, bc.cfg, flat, T_r, T_e, W, L, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_path:
         dist.barrier()
         dist.destroy_process_group()
 

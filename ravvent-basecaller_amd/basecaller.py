@@ -11,6 +11,7 @@ through the host-buffer C entry points (PCIe copies included), CUDA/HIP tensors 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -214,10 +215,13 @@ class Basecaller:
         self.set_option("async_depth", int(depth))
         self.async_depth = int(depth)
 
-    def submit_beam_search(self, input_data, beam_width, max_output_len):
+    supports_out = True       # submit_beam_search / beam_search_stream take caller-provided device outputs
+
+    def submit_beam_search(self, input_data, beam_width, max_output_len, out=None):
         """Queue `beam_search_prediction(input_data, ...)` without waiting for the GPU (rv_beam_search_submit / _submit_dev);
         returns a ticket for `collect`.  Results are byte-identical to the synchronous call.  Device inputs must stay untouched
-        until the ticket is collected (the ticket keeps them alive)."""
+        until the ticket is collected (the ticket keeps them alive).  `out` (device inputs only): a pair of contiguous device
+        tensors (int32 [B, L-1], float32 [B, L-1]) the library writes into instead of fresh ones -- e.g. views into a gather buffer."""
         keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
         L, W = _as_int(max_output_len), int(beam_width)
         steps = max(L - 1, 0)
@@ -225,8 +229,15 @@ class Basecaller:
         call = {"kind": "dev" if on_dev else "host", "keep": keep, "B": B, "steps": steps}
         if on_dev:
             torch.cuda.current_stream(self.device).synchronize()
-            tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
-            scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
+            if out is not None:
+                tokens, scores = out
+                if (tuple(tokens.shape) != (B, steps) or tuple(scores.shape) != (B, steps) or tokens.dtype != torch.int32 or
+                        scores.dtype != torch.float32 or not tokens.is_contiguous() or not scores.is_contiguous() or
+                        tokens.device != self.device or scores.device != self.device):
+                    raise ValueError(f"out: contiguous int32 / float32 tensors of shape {(B, steps)} on {self.device}")
+            else:
+                tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
+                scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
             call["out"] = (tokens, scores)
             rc = self._lib.rv_beam_search_submit_dev(self._h, pr, pe, B, Tr, Te, W, L, ctypes.c_void_p(tokens.data_ptr()),
                                                      ctypes.c_void_p(scores.data_ptr()), ctypes.byref(t))
@@ -286,11 +297,12 @@ class Basecaller:
         self.last_steps = S.value
         return bases, probs, lens
 
-    def beam_search_stream(self, slabs, beam_width, max_output_len, calls: bool = False):
+    def beam_search_stream(self, slabs, beam_width, max_output_len, calls: bool = False, outs=None):
         """Generator: decode an iterable of slabs with `async_depth` of them in flight, yielding each slab's result in order
         ((tokens, scores), or (bases, probs, lengths) with calls=True) -- the overlapped form of a loop over
         `beam_search_prediction` / `beam_search_call_arrays`, with identical results."""
         depth = getattr(self, "async_depth", 2)
+        outs = iter(outs) if outs is not None else None
         sub = self.submit_calls if calls else self.submit_beam_search
         col = self.collect_calls if calls else self.collect
         queue = []
@@ -298,7 +310,10 @@ class Basecaller:
             for x in slabs:
                 if len(queue) >= depth:
                     yield col(queue.pop(0))
-                queue.append(sub(x, beam_width, max_output_len))
+                if outs is not None:       # device inputs: the caller's output tensors, one pair per slab (submit_beam_search's `out`)
+                    queue.append(sub(x, beam_width, max_output_len, out=next(outs)))
+                else:
+                    queue.append(sub(x, beam_width, max_output_len))
             while queue:
                 yield col(queue.pop(0))
         finally:                       # a consumer that stops early (or an error): no ticket may stay uncollected on the handle

@@ -187,12 +187,50 @@ def sharded_beam_search_stream(basecaller, slabs, beam_width: int, max_output_le
         yield finish(queue.pop(0))
 
 
-def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len: int, group=None, slab: int | None = None):
+_MANY: dict = {}
+
+
+def _many_buffers(K, n_max, steps, world, dev, reuse):
+    """(packed [K, F], gathered [world, K, F], tokens [K, world n_max, L-1], score bits likewise), F = 2 n_max (L-1) + n_max."""
+    F = 2 * n_max * steps + n_max
+    def make():
+        return (torch.empty((K, F), dtype=torch.int32, device=dev), torch.empty((world, K, F), dtype=torch.int32, device=dev),
+                torch.empty((K, world * n_max, steps), dtype=torch.int32, device=dev),
+                torch.empty((K, world * n_max, steps), dtype=torch.int32, device=dev))
+    if not reuse:
+        return make()
+    key = (K, n_max, steps, world, str(dev))
+    if key not in _MANY:
+        if len(_MANY) > 8:
+            _MANY.clear()
+        _MANY[key] = make()
+    return _MANY[key]
+
+
+def reserve_many_buffers(basecaller, n_slabs: int, chunks_per_slab: int, max_output_len: int, group=None):
+    """Allocate the gather buffers `sharded_beam_search_many(..., reuse_buffers=True)` will use for a queue of `n_slabs` slabs of
+    `chunks_per_slab` chunks, ahead of time (a service sizes them once; a first-use allocation of a few MB inside a timed region costs
+    more than the collective)."""
+    world = dist.get_world_size(group)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device(getattr(basecaller, "device", None) or torch.device("cuda", torch.cuda.current_device())) if nccl else torch.device("cpu")
+    _many_buffers(int(n_slabs), max(-(-int(chunks_per_slab) // world), 1), max(int(max_output_len) - 1, 0), world, dev, True)
+
+
+def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len: int, group=None, slab: int | None = None,
+                             reuse_buffers: bool = False):
     """A whole queue of FULL slabs (raw, event) with ONE collective at the end (north_star: "read-chunks shard across the GPUs with a
-    single RCCL gather at the end"): every rank streams its shards of all the slabs through the asynchronous calls, packs them into one
-    int32 tensor [K, n_max, 2 (L-1) + 1] (the wire rows of `gather_calls`; n_max = the largest shard of any slab) and one
+    single RCCL gather at the end"): every rank streams its shards of all the slabs through the asynchronous calls and one
     `all_gather_into_tensor` returns everything; no host synchronisation with the other ranks before that.  Returns a list of
-    (tokens [n_k, S_k], scores [n_k, S_k]) in slab order, each identical to `sharded_beam_search` of that slab."""
+    (tokens [n_k, S_k], scores [n_k, S_k]) in slab order, each identical to `sharded_beam_search` of that slab.
+    `reuse_buffers`: gather and result buffers are kept per shape (see `reserve_many_buffers`); the returned tensors are then views
+    that stay valid until the next call with the same shapes.
+
+    Wire format, one int32 row per slab: [token plane n_max x (L-1) | score-bit plane n_max x (L-1) | steps per row n_max] with
+    n_max = the largest shard of any slab.  With device inputs the library writes its results straight into the planes (the
+    `out` tensors of `Basecaller.submit_beam_search`): the host issues no copy per slab.  A row that stopped at step s < S_k (its
+    piece or its shard finished earlier than the slab-wide loop would) is extended after the gather with what that loop emits:
+    the end token at an unchanged score."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     slabs = list(slabs)
     steps = max(int(max_output_len) - 1, 0)
@@ -203,50 +241,69 @@ def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len:
     if K == 0:
         return []
     n_max = max(max(-(-n // world) for n in ns), 1)
-    cols = 2 * steps + 1
+    plane = n_max * steps
     limit = int(slab) if slab else None
-
-    def shards():          # this rank's pieces of every slab, in order; a shard larger than `slab` is cut into several calls
-        for (raw, event), n in zip(slabs, ns):
-            lo, hi = shard_range(n, rank, world)
-            step = limit if limit else max(hi - lo, 1)
-            for a in range(lo, hi, step):
-                b = min(a + step, hi)
-                pick = lambda x: None if x is None else x[a:b]
-                yield {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
-    pieces = [len(range(*shard_range(n, rank, world), limit if limit else max(n, 1))) for n in ns]
-    if hasattr(basecaller, "beam_search_stream"):
-        results = iter(basecaller.beam_search_stream(shards(), beam_width, max_output_len))
-    else:
-        results = (basecaller.beam_search_prediction(x, beam_width=beam_width, max_output_len=max_output_len) for x in shards())
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device(getattr(basecaller, "device", None) or torch.device("cuda", torch.cuda.current_device())) if nccl else torch.device("cpu")
-    packed = torch.empty((K, n_max, cols), dtype=torch.int32, device=dev)
-    packed[:, :, :steps] = end_token
-    packed[:, :, steps:] = 0
-    for k in range(K):
-        row, s_k = 0, 0
-        for _ in range(pieces[k]):
-            tok, sc = next(results)
-            n_loc, s_loc = tok.shape
-            if n_loc and s_loc:
-                scv = sc.to(dev, torch.float32).contiguous()
-                packed[k, row:row + n_loc, :s_loc] = tok.to(dev, torch.int32)
-                packed[k, row:row + n_loc, steps:steps + s_loc] = scv.view(torch.int32)
-                if s_loc < steps:      # a piece that stopped early: unchanged top-1 score on the steps a longer slab-wide loop still runs
-                    packed[k, row:row + n_loc, steps + s_loc:2 * steps] = scv[:, s_loc - 1:s_loc].view(torch.int32)
-            row += n_loc
-            s_k = max(s_k, s_loc)
-        packed[k, :, 2 * steps] = s_k
-    for _ in results:      # (nothing left: the generator collects its tickets)
-        pass
-    gathered = torch.empty((world, K, n_max, cols), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gathered.view(world * K, n_max, cols), packed, group=group)
-    S = gathered[:, :, 0, 2 * steps].max(dim=0).values.tolist()          # per slab: the slab-wide loop runs to the longest shard
+    packed, gathered, tok, sc = _many_buffers(K, n_max, steps, world, dev, reuse_buffers)
+    packed[:, 2 * plane:] = 0                                  # steps per row: 0 = no such row
+    tokP = packed[:, :plane].view(K, n_max, steps)             # views built once: the per-slab host work below is what delays the
+    scP = packed[:, plane:2 * plane].view(K, n_max, steps)     # next submit while the GPU waits for it
+    scPf = scP.view(torch.float32)
+    tok_plane = lambda k: tokP[k]
+    sc_plane = lambda k: scP[k]
+    cuts = []                                                  # (slab, first row, rows, first chunk) of this rank's calls, in order
+    for k, n in enumerate(ns):
+        lo, hi = shard_range(n, rank, world)
+        step = limit if limit else max(hi - lo, 1)
+        cuts += [(k, a - lo, min(a + step, hi) - a, a) for a in range(lo, hi, step)]
+
+    def inputs():
+        for k, _, rows, a in cuts:
+            raw, event = slabs[k]
+            whole = a == 0 and rows == ns[k]
+            pick = lambda x: None if x is None else (x if whole else x[a:a + rows])
+            yield {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
+    first = next((x for x in slabs[0] if x is not None))
+    direct = (getattr(basecaller, "supports_out", False) and torch.is_tensor(first) and first.is_cuda and dev.type == "cuda" and steps > 0)
+    if direct:
+        outs = ((tokP[k, r0:r0 + rows], scPf[k, r0:r0 + rows]) for k, r0, rows, _ in cuts)
+        results = basecaller.beam_search_stream(inputs(), beam_width, max_output_len, outs=outs)
+    elif hasattr(basecaller, "beam_search_stream"):
+        results = basecaller.beam_search_stream(inputs(), beam_width, max_output_len)
+    else:
+        results = (basecaller.beam_search_prediction(x, beam_width=beam_width, max_output_len=max_output_len) for x in inputs())
+    srow_host = torch.zeros((K, n_max), dtype=torch.int32)     # steps per row, filled on the host: ONE copy to the device at the end
+    for (k, r0, rows, _), (tk, ss) in zip(cuts, results):
+        s_loc = int(tk.shape[1])
+        if not direct and rows and s_loc:
+            tok_plane(k)[r0:r0 + rows, :s_loc] = tk.to(dev, torch.int32)
+            sc_plane(k)[r0:r0 + rows, :s_loc] = ss.to(dev, torch.float32).contiguous().view(torch.int32)
+        srow_host[k, r0:r0 + rows] = s_loc
+    packed[:, 2 * plane:] = srow_host.to(dev)
+    dist.all_gather_into_tensor(gathered.view(world * K, 2 * plane + n_max), packed, group=group)
+    # read order: [K, world * n_max, ...], rank-major inside a slab
+    srow = gathered[:, :, 2 * plane:].permute(1, 0, 2).reshape(K, world * n_max)
+    smax = srow.amax(dim=1)
+    ragged = ((srow != smax[:, None]) & (srow > 0)).any()      # some row stopped before its slab's longest one
+    info = torch.cat([smax, ragged[None].to(torch.int32)]).tolist()          # the call's ONE host synchronisation after the gather
+    S, ragged = info[:K], bool(info[K])
+    tok.view(K, world, n_max, steps).copy_(gathered[:, :, :plane].view(world, K, n_max, steps).permute(1, 0, 2, 3))
+    sc.view(K, world, n_max, steps).copy_(gathered[:, :, plane:2 * plane].view(world, K, n_max, steps).permute(1, 0, 2, 3))
+    if steps and ragged:
+        col = torch.arange(steps, device=dev, dtype=torch.int32)
+        past = col[None, None, :] >= srow[:, :, None]          # columns the row's own loop never wrote
+        last = torch.gather(sc, 2, (srow.long() - 1).clamp(min=0)[:, :, None])
+        tok.masked_fill_(past, end_token)
+        sc.copy_(torch.where(past, last.expand_as(sc), sc))
     out = []
     for k, n in enumerate(ns):
-        rows = gathered[:, k].reshape(world * n_max, cols)[_read_order_index(n, world, n_max, dev)]
-        out.append((rows[:, :S[k]].clone(), rows[:, steps:steps + S[k]].clone().view(torch.float32)))
+        if n == world * n_max:
+            tk, ss = tok[k], sc[k]
+        else:
+            idx = _read_order_index(n, world, n_max, dev)
+            tk, ss = tok[k][idx], sc[k][idx]
+        out.append((tk[:, :S[k]], ss[:, :S[k]].view(torch.float32) if S[k] else ss[:, :0].float()))
     return out
 
 
