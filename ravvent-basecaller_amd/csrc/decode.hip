@@ -1099,28 +1099,56 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wq + (size_t)u * RV_U);
     };
     if (BAH) wq_prefetch();
+    if constexpr (MXC) {
+      // W * 128 (beam, unit) items on 512 threads: waves 0-1 take two (W = 5).  Both items' operands are read first, then both are
+      // computed, then stored: the second item rides in the first one's LDS and transcendental latencies instead of doubling the phase.
+      constexpr int NITEM = (W * RV_U + NT - 1) / NT;
+      float z4[NITEM][4], cp[NITEM];
+      bool ok[NITEM];
+#pragma unroll
+      for (int it = 0; it < NITEM; ++it) {
+        const int idx = tid + it * NT;
+        ok[it] = idx < W * RV_U;                             // wave-uniform (128 items per beam, 64 lanes per wave)
+        const int w = ok[it] ? idx >> 7 : 0, u = idx & 127, pb = s_parent[w], tk = s_tok[w];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z4[it][g] = part[pb * ZS + g * RV_U + u] + zb[tk * RV_G + g * RV_U + u];
+        cp[it] = cS[cb * W * RV_U + pb * RV_U + u];
+      }
+#pragma unroll
+      for (int it = 0; it < NITEM; ++it) {
+        if (!ok[it]) continue;
+        const int idx = tid + it * NT, w = idx >> 7, u = idx & 127;
+        const float c2 = fmaf(rv_sigmoid(z4[it][1]), cp[it], rv_sigmoid(z4[it][0]) * rv_tanh(z4[it][2]));
+        const float hh = rv_sigmoid(z4[it][3]) * rv_tanh(c2);
+        cS[(cb ^ 1) * W * RV_U + idx] = c2;
+        qp[idx] = hh * LOG2E;
+        {   // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
+          const float sv = hh * 16384.f;
+          const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+          _Float16* xq = xim + (((RV_U + u) >> 3) * 8 + w) * 8 + (u & 7);
+          xq[0] = hi; xq[2048] = lo;
+        }
+        {   // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
+          const float sv = (hh * LOG2E) * 16384.f;
+          const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+          _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 8 + w) * 8 + (u & 7);
+          qa[0] = hi; qa[1024] = lo;
+        }
+      }
+    } else
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
       const int w = idx >> 7, u = idx & 127, pb = s_parent[w];
       float z4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int col = g * RV_U + u;
-        if constexpr (MXC)
-          z4[g] = part[pb * ZS + col] + zb[s_tok[w] * RV_G + col];
-        else
-          z4[g] = (((part[(0 * W + pb) * RV_G + col] + part[(1 * W + pb) * RV_G + col]) + part[(2 * W + pb) * RV_G + col]) +
+        z4[g] = (((part[(0 * W + pb) * RV_G + col] + part[(1 * W + pb) * RV_G + col]) + part[(2 * W + pb) * RV_G + col]) +
                    part[(3 * W + pb) * RV_G + col]) + zb[s_tok[w] * RV_G + col];
       }
       const float c2 = fmaf(rv_sigmoid(z4[1]), cS[cb * W * RV_U + pb * RV_U + u], rv_sigmoid(z4[0]) * rv_tanh(z4[2]));
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
-      if (D > 1) h0T[u * WB + w] = hh; else { if (!MXC) hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
-      if constexpr (MXC) {     // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
-        const float sv = hh * 16384.f;
-        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-        _Float16* xq = xim + (((RV_U + u) >> 3) * 8 + w) * 8 + (u & 7);
-        xq[0] = hi; xq[2048] = lo;
-      }
+      if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
       if constexpr (MX) {      // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
         const float sv = (hh * LOG2E) * 16384.f;
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
