@@ -285,9 +285,9 @@ def test_split_operands_adversarial_attention(rv, oracle):
     oracle where the split is under the most stress: W_mem and W_att eight times the Keras scale (scores of tens: near one-hot
     alignments), one key column x 100 and one x 1e-5 (a 1e7 range inside one f16-scaled matrix, keys up to ~2,400), one column of
     the attention layer's context rows x 100, a chunk with a SINGLE unmasked step (the alignment is exactly one-hot) and one with
-    three.  The decoder cell is left at Keras scale on purpose: it runs plain fp32 FMAs (no split operand), and at x 8 the decode
-    turns chaotic -- the numpy fp32 twin of the oracle then leaves the fp64 oracle by > 1e-4 at the third step, so a bound there
-    would test nothing.  Per-step logits of every chunk whose beam order equals the fp64 one: within 1e-4; any other chunk must
+    three.  The decoder cell is left at Keras scale on purpose (its own split operands are stressed in
+    test_split_operands_adversarial_cell): at x 8 the decode turns chaotic -- the numpy fp32 twin of the oracle then leaves the fp64
+    oracle by > 1e-4 at the third step, so a bound there would test nothing.  Per-step logits of every chunk whose beam order equals the fp64 one: within 1e-4; any other chunk must
     pass through a near-tie in exact arithmetic."""
     from test_parity_gpu import _near_tie_gap
     B, Tr, Te, W, L = 12, 120, 20, 5, 16
@@ -333,5 +333,60 @@ def test_split_operands_adversarial_attention(rv, oracle):
                 assert gap < TOL, f"matrix_attention={mx}, chunk {b}: differs from fp64 with no near-tie (smallest gap {gap:.3e})"
                 n_tie += 1
         print(f"matrix_attention={mx}: max |logits - fp64| {worst:.2e} over {B - n_tie} chunks, {n_tie} near-tie chunk(s)")
+        assert n_tie <= B // 4, n_tie
+    bc.close()
+
+
+def test_split_operands_adversarial_cell(rv, oracle):
+    """The decoder cell's product on the matrix pipe (matrix_cell = 1, the default: [ctx' | h] . [W_a ; U + A_h W_a] as three exact f16
+    part products, ONE power-of-two scale for the whole kernel, the ctx' rows divided by the scale of the context image) where that
+    split is under stress: the attention layer's context rows x 32 (|ctx'| of several units against |h| < 1, and a context-image bound
+    of hundreds: the two halves of the kernel end up 2^5 apart in the image), one gate column of the cell's attention rows x 50 and one x 1e-4, one recurrent row x 30, one x 1e-5 (a
+    1e6 range inside the one scaled tensor).  Four steps only -- with these weights the cell is a chaotic map and any fp32 evaluation
+    leaves fp64 soon after -- per-step logits of every chunk whose beam order equals the fp64 one within 1e-4, both cell forms; any
+    other chunk must pass through a near-tie in exact arithmetic."""
+    from test_parity_gpu import _near_tie_gap
+    B, Tr, Te, W, L = 10, 150, 25, 5, 5
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=Tr, max_event_len=Te)
+    flat = rv.weights.init_weights(bc.cfg, seed=31)
+    flat["W_att"][128:] *= 32.0
+    flat["dec_cells.0.W"][7:, 5] *= 50.0
+    flat["dec_cells.0.W"][7:, 300] *= 1e-4
+    flat["dec_cells.0.U"][3, :] *= 30.0
+    flat["dec_cells.0.U"][77, :] *= 1e-5
+    flat["W_fc"] *= 0.25
+    flat["b_fc"][bc.cfg.end_token] = -2.0
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=8)
+    bc.set_option("persist_taps", 1)
+    bc.set_option("profile", 1)
+    out = {}
+    for mc in (1, 0):
+        bc.set_option("matrix_cell", mc)
+        tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+        assert "dec_persist" in bc.profile()
+        S = tok.shape[1]
+        out[mc] = (tok.numpy().copy(), sc.numpy().copy(), bc.get_tensor("step_logits").reshape(S, B, W, 7),
+                   bc.get_tensor("parent_ids").reshape(S, B, W), bc.get_tensor("chunk_steps").astype(int))
+    taps = {}
+    ot, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
+    assert np.abs(taps["enc_output"] @ flat["W_att"][128:].astype(np.float64)).max() > 4.0    # the regime: context images of several units
+    end = bc.cfg.oracle_cfg()["end_token"]
+    for mc in (1, 0):
+        tok, sc, lg, par, cs = out[mc]
+        n_tie, worst = 0, 0.0
+        for b in range(B):
+            n = min(cs[b], ot.shape[1])
+            if (par[:n, b] == taps["parent_ids"][:n, b]).all() and (tok[b, :ot.shape[1]] == ot[b]).all():
+                e = float(np.abs(lg[:n, b] - taps["step_logits"][:n, b]).max())
+                worst = max(worst, e)
+                assert e < TOL, (mc, b, e)
+                assert np.abs(sc[b, :ot.shape[1]] - osc[b]).max() < TOL, (mc, b)
+            else:
+                gap = _near_tie_gap(oracle, taps["step_logits"][:, b], W, end)
+                assert gap < TOL, f"matrix_cell={mc}, chunk {b}: differs from fp64 with no near-tie (smallest gap {gap:.3e})"
+                n_tie += 1
+        print(f"matrix_cell={mc}: max |logits - fp64| {worst:.2e} over {B - n_tie} chunks, {n_tie} near-tie chunk(s)")
         assert n_tie <= B // 4, n_tie
     bc.close()

@@ -125,8 +125,9 @@ def test_memory_projection_split_gemm_against_fp64(rv, B, Tr, Te):
 
 @pytest.mark.parametrize("W,Tr,Te", [(2, 40, 9), (5, 200, 30), (7, 300, 45), (5, 300, 45), (1, 17, 3)])
 def test_matrix_attention_matches_fp32_rows_and_oracle(rv, oracle, W, Tr, Te):
-    """rv_set_option("matrix_attention"): scores and context of the persistent decode as split-f16 MFMAs on fragments resident in
-    registers (1, the default) against packed fp32 FMAs on fp32 rows (0): every step's logits within 2e-5 of each other and within
+    """rv_set_option("matrix_attention") / ("matrix_cell"): scores and context of the persistent decode as split-f16 MFMAs on fragments
+    resident in registers, and the decoder cell's product on streamed split-f16 fragments (both on: the default), against packed fp32 FMAs
+    on fp32 rows: every step's logits within 2e-5 of each other and within
     1e-4 of the fp64 oracle, tokens / beam ids / parents identical, at the three memory-length variants of the kernel
     (T_m <= 64, <= 256, <= 352), with padded steps at both ends of the memory and weights scaled up (larger keys)."""
     B, L = 7, 14
@@ -140,8 +141,9 @@ def test_matrix_attention_matches_fp32_rows_and_oracle(rv, oracle, W, Tr, Te):
     bc.set_option("persist_taps", 1)
     bc.set_option("profile", 1)
     got = {}
-    for mx in (1, 0):
-        bc.set_option("matrix_attention", mx)
+    for mx in (2, 1, 0):                          # 2: attention AND the cell product on the matrix pipe (the default), 1: attention only
+        bc.set_option("matrix_attention", 1 if mx else 0)
+        bc.set_option("matrix_cell", 1 if mx == 2 else 0)
         tok, sc = bc.beam_search_prediction((raw, ev), W, L)
         assert "dec_persist" in bc.profile()
         cs = bc.get_tensor("chunk_steps").astype(int)
@@ -150,17 +152,18 @@ def test_matrix_attention_matches_fp32_rows_and_oracle(rv, oracle, W, Tr, Te):
                    bc.get_tensor("step_ids").reshape(S, B, W).copy(), bc.get_tensor("parent_ids").reshape(S, B, W).copy())
     taps = {}
     otok, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
-    for mx in (1, 0):
+    for mx in (2, 1, 0):
         tok, sc, cs, lg, ids, par = got[mx]
         assert tok.shape == otok.shape and (tok == otok).all() and np.abs(sc - osc).max() < TOL, mx
         for b in range(B):
             n = cs[b]
             assert np.abs(lg[:n, b] - taps["step_logits"][:n, b]).max() < TOL, (mx, b)
             assert (ids[:n, b] == taps["step_ids"][:n, b]).all() and (par[:n, b] == taps["parent_ids"][:n, b]).all(), (mx, b)
-    assert (got[1][2] == got[0][2]).all()
+    assert (got[1][2] == got[0][2]).all() and (got[2][2] == got[0][2]).all()
     for b in range(B):
         n = got[1][2][b]
         assert np.abs(got[1][3][:n, b] - got[0][3][:n, b]).max() < 2e-5, b
+        assert np.abs(got[2][3][:n, b] - got[0][3][:n, b]).max() < 2e-5, b
     bc.close()
 
 
@@ -504,7 +507,7 @@ def test_every_documented_option_is_accepted(rv):
     doc = hdr[hdr.index("/* Options:"):hdr.index("int rv_set_option")]
     keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
     assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
-            "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "matrix_attention", "profile",
+            "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "matrix_attention", "matrix_cell", "profile",
             "wide_recurrence", "async_depth"} <= keys
     bc, _ = _mk(rv)
     for k in sorted(keys):

@@ -5,9 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ravvent_basecaller_amd as rv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=300, max_event_len=30, max_output_len=48)
+T_R = int(os.environ.get("RV_T_R", "300"))
+bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_R, max_event_len=30, max_output_len=48)
 bc.init_random_weights(seed=22)
-raw, ev, _ = rv.synthetic.make_slab(B, 300, 30, seed=0)
+raw, ev, _ = rv.synthetic.make_slab(B, T_R, 30, seed=0)
 x = (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
 for _ in range(3):
     bc.beam_search_prediction(x, 5, 48)
