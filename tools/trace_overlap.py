@@ -4,8 +4,8 @@ spans inside it, how many kernels are in flight, and the workgroup demand agains
 Usage: trace_overlap.py <kernel_trace.csv> [K] [W]"""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-W = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20     # the driver's command: --steps 20 --warmup 5
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ev = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
