@@ -333,8 +333,11 @@ def main():
     gc.collect(); gc.disable()             # before the warm-up: a collection between warm-up and timing idles the GPU (~50 ms)
     if dist_path and depth and not args.gather_per_step:   # the gather buffers of the K timed steps, sized ahead of time (a first-use
         rv.dist.reserve_many_buffers(bc, args.steps, n_global, L)   # allocation inside the timed region costs more than the collective)
-    if dist_path:                          # the FIRST barrier of a process group sets its collective up (tens of ms with RCCL): not between
-        dist.barrier()                     # the warm-up and the timed region, where the idle GPU would drop its clocks (see --help of RV_BENCH_GAP_MS)
+    if dist_path:                          # the FIRST use of a collective sets it up (tens of ms with RCCL): not between the warm-up and the
+        dist.barrier()                     # timed region, where the idle GPU would drop its clocks (RV_BENCH_GAP_MS shows what a gap there costs)
+        _g = torch.zeros((world, 8), dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_gather_into_tensor(_g, _g[rank].clone())
+        del _g
     run_steps(max(args.warmup, 1))         # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
     for _ in range(int(os.environ.get("RV_BENCH_PRERUN", "0"))):      # diagnostic: whole untimed passes of the K steps first
         run_steps(args.steps)

@@ -214,7 +214,8 @@ def reserve_many_buffers(basecaller, n_slabs: int, chunks_per_slab: int, max_out
     world = dist.get_world_size(group)
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device(getattr(basecaller, "device", None) or torch.device("cuda", torch.cuda.current_device())) if nccl else torch.device("cpu")
-    _many_buffers(int(n_slabs), max(-(-int(chunks_per_slab) // world), 1), max(int(max_output_len) - 1, 0), world, dev, True)
+    for t in _many_buffers(int(n_slabs), max(-(-int(chunks_per_slab) // world), 1), max(int(max_output_len) - 1, 0), world, dev, True):
+        t.zero_()                                              # (touched once: the first kernels to write them do not find them cold)
 
 
 def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len: int, group=None, slab: int | None = None,
