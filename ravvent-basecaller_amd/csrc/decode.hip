@@ -1316,7 +1316,9 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         mrow_[i] = m;
         if (l16 == 0) { ml[wv * WB + kq + 4 * i] = m; ml[(8 + wv) * WB + kq + 4 * i] = lsum; }
       }
+      RV_STAMP(d, step, 14);
       __syncthreads();
+      RV_STAMP(d, step, 15);
       {
         // merge: lane (beam = lane / 8, wave g = lane % 8) takes one (max, sum) pair; 8-lane butterflies give every lane of the
         // group the beam's maximum and its total (the same instruction sequence in every wave: the same bits in every wave)

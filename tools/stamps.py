@@ -17,7 +17,7 @@ for _ in range(3):
         pn = [("gates", 0, 2), ("att-h", 2, 3), ("scores", 3, 4), ("softmax", 4, 5), ("context", 5, 6), ("merge", 6, 8),
               ("logits", 8, 9), ("beam||cell-GEMV", 9, 10)]
         print(" ".join(f"{n}={ts[j]-ts[i]:.0f}" for n, i, j in pn), "step total", ts[10] - ts[0],
-              f"| beam step (wave 0) {ts[11]-ts[9]:.0f}, wave 1's cell product {ts[13]-ts[12]:.0f} (starts {ts[12]-ts[9]:.0f} after the logits barrier)")
+              f"| softmax: local {ts[14]-ts[4]:.0f} + barrier {ts[15]-ts[14]:.0f} + merge and image {ts[5]-ts[15]:.0f} | beam step (wave 0) {ts[11]-ts[9]:.0f}, wave 1's cell product {ts[13]-ts[12]:.0f} (starts {ts[12]-ts[9]:.0f} after the logits barrier)")
         continue
     names = ["entry", "prologue", "qprime", "sweep", "merge", "E att", "F logits", "G beam", "H/end"]
     print(" ".join(f"{n}={ts[i]-ts[i-1] if i else 0:.0f}" for i, n in enumerate(names[:8])), "total", ts[7])
