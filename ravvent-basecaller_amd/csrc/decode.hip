@@ -943,6 +943,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr bool MXC = ATT == 3;           // ... and the cell product [ctx' | h] . Wcat2 (weights as B fragments from the Wc16 image)
   constexpr int ZS = MXC ? MXC_ZS : RV_G;  // row stride of the gate pre-activations in `part`
   constexpr int NC = mxc_nc(W);
+  constexpr int NR = (MXC && NIT <= 8) ? 5 : 0;   // T_m <= 256 leaves ~50 registers: waves 1-7 keep NR more (k-step, gate) pairs of their share there
   static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
   static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= (ATT == 3 ? part_floats_mxc(W) : part_floats(W)), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
   static_assert(2 * 1024 * sizeof(_Float16) /* query image: 2 parts x [16 k-blocks][8 slots][8] f16 */ <= (8 * 4 * 2 * 16 * 4) * sizeof(float), "the query image must fit `fold`");
@@ -1070,6 +1071,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   for (int i = tid; i < V * RV_G; i += NT) zb[i] = Wtok[i] + bdec[i & (RV_G - 1)];   // W_dec[one_hot(v)] + b, resident
   __syncthreads();
 
+  uint4 rbh[NR > 0 ? NR : 1], rbl[NR > 0 ? NR : 1];       // pairs 32 - NC - NR .. 32 - NC - 1 of this wave, resident for the whole decode
+  if constexpr (NR > 0) {
+    const uint4* wimg = reinterpret_cast<const uint4*>(d.Wc16) + (size_t)(tid >> 6) * (32 * 128) + (tid & 63);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { rbh[r] = wimg[(2 * (32 - NC - NR + r)) * 64]; rbl[r] = wimg[(2 * (32 - NC - NR + r) + 1) * 64]; }
+  }
   int done_steps = steps;
   const int tid0 = tid;
   for (int step = 0; step < steps; ++step) {
@@ -1618,7 +1625,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;
         const uint4* wimg = reinterpret_cast<const uint4*>(d.Wc16) + (size_t)wv * (32 * 128) + lane;   // pair p, part q: [(2 p + q) * 64]
         const _Float16* xa = xim + (kq * 8 + aslot) * 8;     // k-step ks: + 256 ks; low part: + 2048
-        constexpr int NS = 32 - NC, NB = 4;
+        constexpr int NS = 32 - NC - NR, NB = 4;             // streamed pairs
         f4v acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -1663,6 +1670,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             __builtin_amdgcn_sched_barrier(0);
             if (p + NB < NS) { bh[p % NB] = wimg[(2 * (p + NB)) * 64]; bl[p % NB] = wimg[(2 * (p + NB) + 1) * 64]; }
             __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (NR > 0) {                            // the pairs that live in registers
+#pragma unroll
+            for (int r = 0; r < NR; ++r) mm(NS + r, rbh[r], rbl[r]);
           }
         }
         // C/D: lane (column l16, kq) holds rows 4 kq + i = beams kq + 4 i
