@@ -154,10 +154,18 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     cur ^= 1;
     RV_MX_BARRIER();
   };
-  for (int s = 0; s < T; s += 3) {
+  // whole triples in the loop, the one or two steps that are left after it: a conditional step INSIDE the loop makes the compiler merge
+  // two histories of pending loads / stores at the loop header, and it then drains the vector-memory counter there (`s_waitcnt vmcnt(0)`
+  // once per three steps: the wave waited for the previous step's output store and for inputs it had requested one step earlier)
+  int s = 0;
+  for (; s + 2 < T; s += 3) {
+    step(s, xc, xnn);
+    step(s + 1, xn, xc);
+    step(s + 2, xnn, xn);
+  }
+  if (s < T) {
     step(s, xc, xnn);
     if (s + 1 < T) step(s + 1, xn, xc);
-    if (s + 2 < T) step(s + 2, xnn, xn);
   }
   if (live) {
     *reinterpret_cast<float4*>(a.hT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
