@@ -250,7 +250,12 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
           al[m][j] = (_Float16)(sv - (float)ah[m][j]);
         }
       }
-      if (!(dbg & 2)) {                                    // stream position + 2, into the registers just consumed
+#ifdef RV_GEMM_DIAG
+      if (!(dbg & 2))
+#endif
+      {                                                    // stream position + 2, into the registers just consumed.  (Unconditional in
+        // the product build: a run-time condition around these loads makes the compiler merge "requested" and "not requested" at the
+        // next k-step and drain the vector-memory counter there -- the loads were then waited for one k-step after their request, not two)
         if (ks & 1) RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a1); else RV_A_LOAD(ks + 2 < 8 ? tile : tnext, (ks + 2) & 7, a0);
       }
       const char* bs = Bs[(8 * n + ks) % 3] + lane * 16;
