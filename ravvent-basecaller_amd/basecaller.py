@@ -217,11 +217,13 @@ class Basecaller:
 
     supports_out = True       # submit_beam_search / beam_search_stream take caller-provided device outputs
 
-    def submit_beam_search(self, input_data, beam_width, max_output_len, out=None):
+    def submit_beam_search(self, input_data, beam_width, max_output_len, out=None, out_ptrs=None):
         """Queue `beam_search_prediction(input_data, ...)` without waiting for the GPU (rv_beam_search_submit / _submit_dev);
         returns a ticket for `collect`.  Results are byte-identical to the synchronous call.  Device inputs must stay untouched
         until the ticket is collected (the ticket keeps them alive).  `out` (device inputs only): a pair of contiguous device
-        tensors (int32 [B, L-1], float32 [B, L-1]) the library writes into instead of fresh ones -- e.g. views into a gather buffer."""
+        tensors (int32 [B, L-1], float32 [B, L-1]) the library writes into instead of fresh ones -- e.g. views into a gather buffer.
+        `out_ptrs` (device inputs only): the same as two raw device addresses (the caller vouches for room, type and lifetime; `collect`
+        then returns only the step count) -- a loop that submits thousands of slabs into one buffer saves the per-slab tensor views."""
         keep, pr, pe, B, Tr, Te, on_dev = self._gather_inputs(input_data)
         L, W = _as_int(max_output_len), int(beam_width)
         steps = max(L - 1, 0)
@@ -229,6 +231,12 @@ class Basecaller:
         call = {"kind": "dev" if on_dev else "host", "keep": keep, "B": B, "steps": steps}
         if on_dev:
             torch.cuda.current_stream(self.device).synchronize()
+            if out_ptrs is not None:
+                rc = self._lib.rv_beam_search_submit_dev(self._h, pr, pe, B, Tr, Te, W, L, ctypes.c_void_p(int(out_ptrs[0])),
+                                                         ctypes.c_void_p(int(out_ptrs[1])), ctypes.byref(t))
+                self._check(rc, "rv_beam_search_submit")
+                call["kind"] = "dev_ptrs"; call["ticket"] = t.value
+                return call
             if out is not None:
                 tokens, scores = out
                 if (tuple(tokens.shape) != (B, steps) or tuple(scores.shape) != (B, steps) or tokens.dtype != torch.int32 or
@@ -250,6 +258,11 @@ class Basecaller:
     def collect(self, call):
         """Wait for a `submit_beam_search` ticket -> (predicted_ids[:,:,0] [B,S] int32, scores[:,:,0] [B,S] f32)."""
         S = ctypes.c_int32(0)
+        if call["kind"] == "dev_ptrs":     # results went to the caller's addresses: only the step count comes back
+            self._check(self._lib.rv_beam_search_collect_dev(self._h, call["ticket"], ctypes.byref(S)), "rv_beam_search_collect_dev")
+            call["keep"] = None
+            self.last_steps = S.value
+            return S.value
         if call["kind"] == "dev":
             self._check(self._lib.rv_beam_search_collect_dev(self._h, call["ticket"], ctypes.byref(S)), "rv_beam_search_collect_dev")
             tokens, scores = call["out"]

@@ -247,10 +247,8 @@ def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len:
     nccl = dist.get_backend(group) == "nccl"
     dev = torch.device(getattr(basecaller, "device", None) or torch.device("cuda", torch.cuda.current_device())) if nccl else torch.device("cpu")
     packed, gathered, tok, sc = _many_buffers(K, n_max, steps, world, dev, reuse_buffers)
-    packed[:, 2 * plane:] = 0                                  # steps per row: 0 = no such row
     tokP = packed[:, :plane].view(K, n_max, steps)             # views built once: the per-slab host work below is what delays the
     scP = packed[:, plane:2 * plane].view(K, n_max, steps)     # next submit while the GPU waits for it
-    scPf = scP.view(torch.float32)
     tok_plane = lambda k: tokP[k]
     sc_plane = lambda k: scP[k]
     cuts = []                                                  # (slab, first row, rows, first chunk) of this rank's calls, in order
@@ -267,19 +265,42 @@ def sharded_beam_search_many(basecaller, slabs, beam_width: int, max_output_len:
             yield {"joint": (pick(raw), pick(event)), "raw": pick(raw), "event": pick(event)}[mode]
     first = next((x for x in slabs[0] if x is not None))
     direct = (getattr(basecaller, "supports_out", False) and torch.is_tensor(first) and first.is_cuda and dev.type == "cuda" and steps > 0)
+    steps_of = []                                              # (slab, first row, rows, steps) per call
     if direct:
-        outs = ((tokP[k, r0:r0 + rows], scPf[k, r0:r0 + rows]) for k, r0, rows, _ in cuts)
-        results = basecaller.beam_search_stream(inputs(), beam_width, max_output_len, outs=outs)
-    elif hasattr(basecaller, "beam_search_stream"):
-        results = basecaller.beam_search_stream(inputs(), beam_width, max_output_len)
+        # device inputs: the library writes every call's tokens and scores straight into the planes -- raw addresses, so that the host
+        # does nothing per slab but submit and collect (its time per slab is what the GPU waits for whenever the queue runs low)
+        base, depth, queue = packed.data_ptr(), max(int(getattr(basecaller, "async_depth", 2)), 1), []
+        def finish(item):
+            c, call = item
+            steps_of.append((c[0], c[1], c[2], basecaller.collect(call)))
+        try:
+            for c, x in zip(cuts, inputs()):
+                if len(queue) >= depth:
+                    finish(queue.pop(0))
+                k, r0 = c[0], c[1]
+                off = 4 * (k * (2 * plane + n_max) + r0 * steps)
+                queue.append((c, basecaller.submit_beam_search(x, beam_width, max_output_len, out_ptrs=(base + off, base + off + 4 * plane))))
+            while queue:
+                finish(queue.pop(0))
+        finally:                                               # (an error: no ticket may stay uncollected on the handle)
+            while queue:
+                try:
+                    basecaller.collect(queue.pop(0)[1])
+                except Exception:
+                    pass
     else:
-        results = (basecaller.beam_search_prediction(x, beam_width=beam_width, max_output_len=max_output_len) for x in inputs())
-    srow_host = torch.zeros((K, n_max), dtype=torch.int32)     # steps per row, filled on the host: ONE copy to the device at the end
-    for (k, r0, rows, _), (tk, ss) in zip(cuts, results):
-        s_loc = int(tk.shape[1])
-        if not direct and rows and s_loc:
-            tok_plane(k)[r0:r0 + rows, :s_loc] = tk.to(dev, torch.int32)
-            sc_plane(k)[r0:r0 + rows, :s_loc] = ss.to(dev, torch.float32).contiguous().view(torch.int32)
+        if hasattr(basecaller, "beam_search_stream"):
+            results = basecaller.beam_search_stream(inputs(), beam_width, max_output_len)
+        else:
+            results = (basecaller.beam_search_prediction(x, beam_width=beam_width, max_output_len=max_output_len) for x in inputs())
+        for (k, r0, rows, _), (tk, ss) in zip(cuts, results):
+            s_loc = int(tk.shape[1])
+            if rows and s_loc:
+                tok_plane(k)[r0:r0 + rows, :s_loc] = tk.to(dev, torch.int32)
+                sc_plane(k)[r0:r0 + rows, :s_loc] = ss.to(dev, torch.float32).contiguous().view(torch.int32)
+            steps_of.append((k, r0, rows, s_loc))
+    srow_host = torch.zeros((K, n_max), dtype=torch.int32)     # steps per row, filled on the host: ONE copy to the device
+    for k, r0, rows, s_loc in steps_of:
         srow_host[k, r0:r0 + rows] = s_loc
     packed[:, 2 * plane:] = srow_host.to(dev)
     dist.all_gather_into_tensor(gathered.view(world * K, 2 * plane + n_max), packed, group=group)
