@@ -144,6 +144,10 @@ struct DecState {
   // (k < 128) and 2^14 for the h rows -- the factors the inputs' f16 images carry -- and T the power of two that brings the largest
   // such element into [2^13, 2^14); mx_cdescale = 1 / T
   const uint16_t* Wc16; float mx_cdescale;
+  // ... and the output layer of that decode: Wl16 = [W_fc ; A_h W_fc] [256][16 (V padded)] as B fragments of two f16 parts,
+  // [8 k-steps][2 parts][64 lanes][8 f16] (16 KB), rows divided like Wc16's, one power-of-two scale; mx_ldescale = its inverse.
+  // Wave 0 takes the logits of all beams as 24 MFMAs on the [ctx' | h] image while the other waves already stream the cell product
+  const uint16_t* Wl16; float mx_ldescale;
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

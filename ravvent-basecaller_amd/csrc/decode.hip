@@ -887,12 +887,12 @@ __host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PER
 // padded so that the four beams a wave stores at once fall into different banks).  Weight cache in LDS: ALL 32 (k-step, gate) pairs
 // of wave 0 (64 KB) -- wave 0 takes the beam step first (5 k cycles) and would stream its share alone afterwards -- and the last
 // mxc_nc(W) pairs of each of the other seven waves (2 KB per pair and wave)
-__host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 2 : 1; }
+__host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 1 : 0; }   // (2 / 1 before the output layer's fragments took 16 KB)
 __host__ __device__ constexpr int mxc_cache_floats(int W) { return (32 + 7 * mxc_nc(W)) * 512; }
 constexpr int MXC_ZS = RV_G + 16;
 __host__ __device__ constexpr int part_floats_mxc(int W) { return W * MXC_ZS > PERSIST_MAX_NIT * 256 ? W * MXC_ZS : PERSIST_MAX_NIT * 256; }
 struct PersistLds {
-  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, xim, wcache, total;
+  int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, xim, wl16, wcache, total;
   // ATT: 0 Luong on fp32 rows, 1 Bahdanau, 2 Luong on the matrix pipe, 3 = 2 + the cell product on the matrix pipe
   __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
     const bool mxc = ATT == 3;
@@ -925,6 +925,8 @@ struct PersistLds {
     }
     xim = o;
     if (mxc) o += 2048;                // [ctx' | h] of the beams as MFMA A fragments: [2 parts][32 k-blocks][8 slots][8] f16
+    wl16 = o;
+    if (mxc) o += 4096;                // the output layer [W_fc ; A_h W_fc] as B fragments (DecState::Wl16, 16 KB): wave 0's logits
     wcache = o;
     if (mxc) o += mxc_cache_floats(W);
     else if (persist_weight_cache(W, D)) o += 24 * RV_G;   // 24 rows of the cell kernel kept in LDS (48 KB): the last 8 rows of K groups 1-3
@@ -1050,11 +1052,17 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   for (int i = tid; i < RV_U * V; i += NT) s_wfc[(i % V) * FCW + i / V] = d.W_fc[i];
   if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[(i % V) * FCW + i / V] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
   if (tid < V) s_wfc[RV_MAX_VOCAB * FCW + tid] = d.b_fc[tid];
+  if (MXC) {   // the output layer's fragments
+    const uint4* src = reinterpret_cast<const uint4*>(d.Wl16);
+    uint4* dst = reinterpret_cast<uint4*>(dsm + L.wl16);
+    for (int i = tid; i < 1024; i += NT) dst[i] = src[i];
+  }
   if (MXC) {   // wave 0's 32 pairs, then the last NC pairs of waves 1-7: 2 KB each, in image order
     const uint4* src = reinterpret_cast<const uint4*>(d.Wc16);
     uint4* dst = reinterpret_cast<uint4*>(wcache);
     for (int i = tid; i < 32 * 128; i += NT) dst[i] = src[i];
-    for (int i = tid; i < 7 * NC * 128; i += NT) dst[32 * 128 + i] = src[(size_t)((1 + i / (NC * 128)) * 32 + 32 - NC) * 128 + i % (NC * 128)];
+    if constexpr (NC > 0)
+      for (int i = tid; i < 7 * NC * 128; i += NT) dst[32 * 128 + i] = src[(size_t)((1 + i / (NC * 128)) * 32 + 32 - NC) * 128 + i % (NC * 128)];
   } else if (CACHE) {
     for (int i = tid; i < 24 * (RV_G / 4); i += NT) {
       const int r = i >> 7, c = i & 127;
@@ -1508,7 +1516,39 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     __syncthreads();
     }
     RV_STAMP(d, step, 8);
-    // ================= logits = attention . W_fc + b_fc: 8 lanes per output, all W*V <= 35 outputs in one pass
+    // ================= logits = attention . W_fc + b_fc
+    if constexpr (MXC) {
+      // Matrix-pipe cell product: the logits are ONE 16-column tile over the beams' [ctx' | h] image (the cell product's A operand),
+      // 24 MFMAs that wave 0 takes alone, B fragments from the LDS copy of the 16 KB Wl16 image (from L2 the same reads queue behind
+      // the other waves' weight stream: 4.4 k cycles) -- the other waves go straight on to the cell product (they only need ctx' and
+      // h): no logits phase and no barrier in front of the beam step.
+      if (wv == 0) {
+        const int l16 = lane & 15, kq = lane >> 4;
+        const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;
+        const _Float16* xa = xim + (kq * 8 + aslot) * 8;
+        const uint4* wl = reinterpret_cast<const uint4*>(dsm + L.wl16) + lane;
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint4 bh[4], bl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { bh[i] = wl[(2 * (4 * half + i)) * 64]; bl[i] = wl[(2 * (4 * half + i) + 1) * 64]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ks = 4 * half + i;
+            const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
+            const h8 wh = __builtin_bit_cast(h8, bh[i]), wlo = __builtin_bit_cast(h8, bl[i]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wlo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc, 0, 0, 0);
+          }
+        }
+        constexpr int NI = W > 4 ? 2 : 1;               // C/D: lane (column v = l16, kq) holds beams kq + 4 i
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (kq + 4 * i < W && l16 < V) lg[(kq + 4 * i) * RV_MAX_VOCAB + l16] = acc[i] * d.mx_ldescale + s_wfc[RV_MAX_VOCAB * FCW + l16];
+      }
+    } else {
     {
       const int o8 = tid >> 3, s8 = tid & 7;
       if (o8 < W * V) {                                     // whole 8-lane groups take the branch together
@@ -1539,6 +1579,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
     }
     __syncthreads();
+    }
     RV_STAMP(d, step, 9);
     // ================= beam step (wave 0): log-softmax, finished masking, top-W, bookkeeping
     if (tid < 64) {

@@ -65,6 +65,8 @@ struct RvContext {
   int opt_mx_att = 1;                       // persistent decode (Luong, one cell): attention on the matrix pipe
   int opt_mx_cell = 1;                      // ... and its cell product [ctx' | h] . Wcat2 as well (needs opt_mx_att)
   float mx_cdescale = 1.f;                  // 1 / the power-of-two scale of the Wc16 image (set by rv_load_weights)
+  float mx_ldescale = 1.f;                  // ... of the Wl16 image
+  uint16_t* d_Wl16 = nullptr;               // derived (one decoder cell): [W_fc ; A_h W_fc] as MFMA B fragments (DecState::Wl16)
   float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
   uint16_t* d_Ua = nullptr;                 // derived: recurrent kernels as MFMA A fragments (two f16 parts) + row factors, [enc][layer][dir][RV_UA_SLOT]
   uint16_t* d_Wx16 = nullptr;               // derived: input kernels of encoder layers >= 1, both directions, as the split GEMM's B slabs, [enc][layer-1][RV_WX16_SLOT]
@@ -527,7 +529,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
   d.chunk_steps = nullptr;
   d.mx_attention = (h->opt_mx_att && c.attention == RV_ATT_LUONG && d.depth == 1) ? (h->opt_mx_cell ? 2 : 1) : 0;   // (sizes the decode's LDS)
-  d.Wc16 = h->d_Wc16; d.mx_cdescale = h->mx_cdescale;
+  d.Wc16 = h->d_Wc16; d.mx_cdescale = h->mx_cdescale; d.Wl16 = h->d_Wl16; d.mx_ldescale = h->mx_ldescale;
   h->lpersist = (persist_ok && dec_persist_supported(d)) ? 1 : 0;
   if (persist_ok && !h->lpersist) return fail(h, RV_ESTATE, "internal: persistent decode predicate mismatch");
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
@@ -763,7 +765,7 @@ int create_child(RvContext* p, RvContext** out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(p, RV_EHIP, "hipStreamCreate failed for an asynchronous context"); }
   h->d_w = p->d_w; h->n_w = p->n_w;
   h->d_WmemT = p->d_WmemT; h->d_Up = p->d_Up; h->d_Wp = p->d_Wp; h->d_Wsb = p->d_Wsb; h->d_Wh = p->d_Wh; h->d_Ua = p->d_Ua;
-  h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16; h->d_Wc16 = p->d_Wc16;
+  h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16; h->d_Wc16 = p->d_Wc16; h->d_Wl16 = p->d_Wl16;
   h->d_WcatT = p->d_WcatT;
   bind_weights(h);
   const int rc = alloc_slab_buffers(h);
@@ -776,7 +778,7 @@ int create_child(RvContext* p, RvContext** out) {
 void sync_child(RvContext* k, const RvContext* p) {
   k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
   k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
-  k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->opt_tail_wave = p->opt_tail_wave;
+  k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->mx_ldescale = p->mx_ldescale; k->opt_tail_wave = p->opt_tail_wave;
   k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
   k->opt_taps = 0; k->opt_ptaps = 0;      // debug taps belong to the synchronous calls
   k->inflight_hint = p->inflight_hint;
@@ -836,6 +838,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
   TRY(dalloc(h, &h->d_Wmp16, RV_WMP16_SLOT));
   TRY(dalloc(h, &h->d_Wc16, (size_t)2 * RV_E * RV_G));
+  TRY(dalloc(h, &h->d_Wl16, (size_t)2 * RV_E * 16));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
@@ -1119,6 +1122,30 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
                 img[(((((size_t)wv * 32 + pr) * 2 + 1) * 64) + ln) * 8 + j] = lb;
               }
         HIPCHK(h, hipMemcpy(h->d_Wc16, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        // the output layer on the same [ctx' | h] image: logits = ctx' . W_fc + h . (A_h W_fc) + b_fc; columns >= V are zero
+        auto wl = [&](int k, int v) -> float {
+          if (v >= V) return 0.f;
+          return (k < RV_U ? blob[fc + (size_t)k * V + v] : nh[(size_t)(k - RV_U) * V + v]) / xs(k);
+        };
+        float ml = 0.f;
+        for (int k = 0; k < RV_E; ++k)
+          for (int v = 0; v < V; ++v) ml = std::max(ml, std::fabs(wl(k, v)));
+        int el = 0;
+        if (ml > 0.f && std::isfinite(ml)) std::frexp(ml, &el);
+        const float Tl = std::ldexp(1.0f, 14 - el);
+        h->mx_ldescale = 1.0f / Tl;
+        std::vector<uint16_t> li((size_t)2 * RV_E * 16);
+        for (int ks = 0; ks < 8; ++ks)
+          for (int ln = 0; ln < 64; ++ln)
+            for (int j = 0; j < 8; ++j) {
+              const float v = wl(32 * ks + 8 * (ln >> 4) + j, ln & 15) * Tl;
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+              li[(((size_t)ks * 2 + 0) * 64 + ln) * 8 + j] = hb;
+              li[(((size_t)ks * 2 + 1) * 64 + ln) * 8 + j] = lb;
+            }
+        HIPCHK(h, hipMemcpy(h->d_Wl16, li.data(), li.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       }
     }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]
