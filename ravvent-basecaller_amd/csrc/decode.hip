@@ -887,7 +887,8 @@ __host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PER
 // padded so that the four beams a wave stores at once fall into different banks).  Weight cache in LDS: ALL 32 (k-step, gate) pairs
 // of wave 0 (64 KB) -- wave 0 takes the beam step first (5 k cycles) and would stream its share alone afterwards -- and the last
 // mxc_nc(W) pairs of each of the other seven waves (2 KB per pair and wave)
-__host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 1 : 0; }   // (2 / 1 before the output layer's fragments took 16 KB)
+__host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 2 : 1; }
+constexpr int MXC_STATIC_LDS = 1024;     // static LDS of the matrix-pipe instantiations (bias, beam bookkeeping): the others keep ~8.7 KB of output layer
 __host__ __device__ constexpr int mxc_cache_floats(int W) { return (32 + 7 * mxc_nc(W)) * 512; }
 constexpr int MXC_ZS = RV_G + 16;
 __host__ __device__ constexpr int part_floats_mxc(int W) { return W * MXC_ZS > PERSIST_MAX_NIT * 256 ? W * MXC_ZS : PERSIST_MAX_NIT * 256; }
@@ -900,7 +901,7 @@ struct PersistLds {
     attT = o; if (!mxc) o += RV_U * WB;   // attention vectors k-major beam-minor (cell input rows 0..127); mxc: the f16 image `xim` instead
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
     cS = o; o += 2 * W * RV_U;         // cell states, double-buffered: the new state of beam w comes from its parent's
-    qp = o; o += W * RV_U;             // h * log2(e): the score query
+    qp = o; if (!mxc) o += W * RV_U;   // h * log2(e): the score query (fp32 rows) and the output layer's h part
     part = o; o += mxc ? part_floats_mxc(W) : part_floats(W);     // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
                                        // layer's h-part partial sums [16][W][128] (after the gates -> merge)
     ctxp = part;                       // context partial sums of the 8 waves [8][W][128]: one cell -> inside `part` (idle between
@@ -908,7 +909,7 @@ struct PersistLds {
     fold = o; o += mxc ? 1024 : 8 * 4 * 2 * 16 * 4;   // (mxc: only the query image, 2 parts x 1024 f16)   wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
                                        // second cell's recurrent partial sums [3][W][512] between the end of a step and its gates
     hcT = o; if (!mxc) o += RV_U * WB;  // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
-    att = o; o += W * RV_U;
+    att = o; if (!mxc) o += W * RV_U;
     ml = o; o += 64 * WB;              // per-stream max [32][WB], per-stream sum [32][WB]
     mg = o; o += 2 * WB;               // merged max, 1/sum
     lg = o; o += WB * RV_MAX_VOCAB;
@@ -961,8 +962,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (spans ctxp + fold)
   // output layer weights, transposed to [v][k] (rows padded to 132 floats: the 8-lane groups of two outputs then read different banks)
   constexpr int FCW = RV_U + 4;
-  __shared__ __align__(16) float s_wfc[RV_MAX_VOCAB * FCW + RV_MAX_VOCAB];
-  __shared__ __align__(16) float s_nh[D == 1 ? RV_MAX_VOCAB * FCW : 4];
+  // (the matrix-pipe form takes the output layer from the Wl16 fragments: it only needs the bias here, and neither `qp` nor `att`)
+  __shared__ __align__(16) float s_wfc[(ATT == 3 ? 0 : RV_MAX_VOCAB * FCW) + RV_MAX_VOCAB];
+  __shared__ __align__(16) float s_nh[(D == 1 && ATT != 3) ? RV_MAX_VOCAB * FCW : 4];
+  constexpr int BFC = ATT == 3 ? 0 : RV_MAX_VOCAB * FCW;      // offset of b_fc in s_wfc
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
 
@@ -1049,9 +1052,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     for (int i = tid; i < 3 * W * RV_G; i += NT) partU[i] = 0.f;
     b1s[tid] = bdec1[tid];
   }
-  for (int i = tid; i < RV_U * V; i += NT) s_wfc[(i % V) * FCW + i / V] = d.W_fc[i];
-  if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[(i % V) * FCW + i / V] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
-  if (tid < V) s_wfc[RV_MAX_VOCAB * FCW + tid] = d.b_fc[tid];
+  if (!MXC) {
+    for (int i = tid; i < RV_U * V; i += NT) s_wfc[(i % V) * FCW + i / V] = d.W_fc[i];
+    if (D == 1) for (int i = tid; i < RV_U * V; i += NT) s_nh[(i % V) * FCW + i / V] = Nh[i] * (1.0f / LOG2E);   // applied to qp = h * log2(e), the row-major copy of h
+  }
+  if (tid < V) s_wfc[BFC + tid] = d.b_fc[tid];
   if (MXC) {   // the output layer's fragments
     const uint4* src = reinterpret_cast<const uint4*>(d.Wl16);
     uint4* dst = reinterpret_cast<uint4*>(dsm + L.wl16);
@@ -1136,7 +1141,6 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         const float c2 = fmaf(rv_sigmoid(z4[it][1]), cp[it], rv_sigmoid(z4[it][0]) * rv_tanh(z4[it][2]));
         const float hh = rv_sigmoid(z4[it][3]) * rv_tanh(c2);
         cS[(cb ^ 1) * W * RV_U + idx] = c2;
-        qp[idx] = hh * LOG2E;
         {   // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
           const float sv = hh * 16384.f;
           const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
@@ -1386,7 +1390,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           if (kq + 4 * i < W) {
-            const float av = acc[i] * d.mx_udescale; att[(kq + 4 * i) * RV_U + col] = av;
+            const float av = acc[i] * d.mx_udescale;
+            if constexpr (!MXC) att[(kq + 4 * i) * RV_U + col] = av;
             if constexpr (MXC) {   // ctx' as A fragments of the cell product: k = col, ctx' . mx_uscale (= acc 2^-14, below 2^14) in two f16 parts
               const float sv = acc[i] * (1.0f / 16384.f);
               const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
@@ -1546,7 +1551,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         constexpr int NI = W > 4 ? 2 : 1;               // C/D: lane (column v = l16, kq) holds beams kq + 4 i
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-          if (kq + 4 * i < W && l16 < V) lg[(kq + 4 * i) * RV_MAX_VOCAB + l16] = acc[i] * d.mx_ldescale + s_wfc[RV_MAX_VOCAB * FCW + l16];
+          if (kq + 4 * i < W && l16 < V) lg[(kq + 4 * i) * RV_MAX_VOCAB + l16] = acc[i] * d.mx_ldescale + s_wfc[BFC + l16];
       }
     } else {
     {
@@ -1575,7 +1580,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         p += dpp<0xB1>(p);    // quad_perm [1,0,3,2]
         p += dpp<0x4E>(p);    // quad_perm [2,3,0,1]
         p += dpp<0x141>(p);   // row_half_mirror: the other quad of this 8-lane group
-        if (s8 == 0) lg[w * RV_MAX_VOCAB + v] = p + s_wfc[RV_MAX_VOCAB * FCW + v];
+        if (s8 == 0) lg[w * RV_MAX_VOCAB + v] = p + s_wfc[BFC + v];
       }
     }
     __syncthreads();
@@ -1916,7 +1921,8 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
   else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, d.attention == 1 ? 1 : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0)).total + 10 * 1024 > 160 * 1024) return false;   // dynamic + static LDS
+  const int att_form = d.attention == 1 ? 1 : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0);
+  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, att_form).total + (att_form == 3 ? MXC_STATIC_LDS : 10 * 1024) > 160 * 1024) return false;   // dynamic + static LDS
   return (d.attention == 0 || (d.attention == 1 && d.depth == 1)) && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
@@ -2011,9 +2017,14 @@ static hipError_t configure_w() {
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
   opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 2>), sizeof(float) * PersistLds(W, 1).total);
-  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
-  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
-  opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  auto opt3 = [&](const void* f, size_t bytes) {       // (more dynamic LDS than `cap`: their static part is ~1 KB)
+    const size_t cap3 = 160 * 1024 - MXC_STATIC_LDS;
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < cap3 ? bytes : cap3));
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  };
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
   if constexpr (W <= 5) {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);
