@@ -20,7 +20,7 @@ LIMITS = {
     r"k_dec_persistILi5ELi11ELi1ELi1E": 64,      # C3 with Bahdanau (28 B today)
     r"k_dec_persistILi5ELi11ELi1ELi2E": 24,      # C3 with the attention on the matrix pipe (20 B today; 100 B in round 2)
     r"k_dec_persistILi5ELi8ELi1ELi2E": 0,        # R
-    r"k_dec_persistILi5ELi11ELi1ELi3E": 24,      # C3, attention AND cell product on the matrix pipe: the default since round 3 (20 B today)
+    r"k_dec_persistILi5ELi11ELi1ELi3E": 8,       # C3, attention, cell product and output layer on the matrix pipe: the default since round 3 (0 B today)
     r"k_dec_persistILi5ELi8ELi1ELi3E": 0,        # R, the same
     r"k_lstm_rec_projILi2ELi[012]EE": 0,         # C3 fused recurrence + projection (f32, split-bf16 and split-f16 MFMA forms)
     r"k_gemm_mem_split3": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
