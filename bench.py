@@ -348,7 +348,7 @@ def main():
     if dist_path:                          # the FIRST use of a collective sets it up (tens of ms with RCCL): not between the warm-up and the
         dist.barrier()                     # timed region, where the idle GPU would drop its clocks (RV_BENCH_GAP_MS shows what a gap there costs)
         _g = torch.zeros((world, 8), dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_gather_into_tensor(_g, _g[rank].clone())
+        dist.all_gather_into_tensor(_g, _g[rank:rank + 1].clone())
         del _g
     run_steps(max(args.warmup, 1))         # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
     for _ in range(int(os.environ.get("RV_BENCH_PRERUN", "0"))):      # diagnostic: whole untimed passes of the K steps first
