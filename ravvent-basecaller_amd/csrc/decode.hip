@@ -226,7 +226,10 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
 
 constexpr int WB = RV_MAX_BEAM;
 constexpr int ATT_THREADS = 512;
-#define RV_STAMP_W1(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 64 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef RV_STAMP_WAVE
+#define RV_STAMP_WAVE 1      // which wave stamps its cell product (diagnostic builds may pick another: make decvar DECFLAGS=-DRV_STAMP_WAVE=4)
+#endif
+#define RV_STAMP_W1(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 64 * RV_STAMP_WAVE && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 #define RV_STAMP(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 0 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 constexpr float LOG2E = 1.4426950408889634f;
 
