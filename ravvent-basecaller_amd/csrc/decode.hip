@@ -888,8 +888,9 @@ constexpr int PERSIST_MAX_NIT = 11;      // resident row groups of 32 steps: T_m
 __host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PERSIST_MAX_NIT * 256 ? 4 * W * RV_G : PERSIST_MAX_NIT * 256; }
 // ATT == 3 (matrix-pipe cell product): gate pre-activations z~ [W][RV_G + 16] (one plane: the product is complete inside a wave; rows
 // padded so that the four beams a wave stores at once fall into different banks).  Weight cache in LDS: ALL 32 (k-step, gate) pairs
-// of wave 0 (64 KB) -- wave 0 takes the beam step first (5 k cycles) and would stream its share alone afterwards -- and the last
-// mxc_nc(W) pairs of each of the other seven waves (2 KB per pair and wave)
+// of wave 0 (64 KB) -- wave 0 takes the output layer and the beam step first (4.7 k cycles) and would stream its share alone afterwards --
+// and the last mxc_nc(W) pairs of each of the other seven waves (2 KB per pair and wave); the output layer's fragments (Wl16, 16 KB) sit in
+// LDS as well.  This form needs neither `qp` / `att` (fp32 copies of h and ctx') nor `attT` / `hcT` nor the fp32 output layer in static LDS
 __host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 2 : 1; }
 constexpr int MXC_STATIC_LDS = 1024;     // static LDS of the matrix-pipe instantiations (bias, beam bookkeeping): the others keep ~8.7 KB of output layer
 __host__ __device__ constexpr int mxc_cache_floats(int W) { return (32 + 7 * mxc_nc(W)) * 512; }
