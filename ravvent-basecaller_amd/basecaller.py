@@ -161,7 +161,8 @@ class Basecaller:
             if x.is_cuda:
                 if x.device != self.device:
                     raise ValueError(f"input on {x.device}, basecaller on {self.device}")
-                t = x.detach().to(torch.float32).contiguous()
+                # (the usual case costs nothing: a submit's host time is what the GPU waits for when the queue runs low)
+                t = x if (x.dtype == torch.float32 and x.is_contiguous() and not x.requires_grad) else x.detach().to(torch.float32).contiguous()
                 return t, ctypes.c_void_p(t.data_ptr()), t.shape[0], t.shape[1], True
             x = x.detach().cpu().numpy()
         a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
@@ -244,8 +245,8 @@ class Basecaller:
                         tokens.device != self.device or scores.device != self.device):
                     raise ValueError(f"out: contiguous int32 / float32 tensors of shape {(B, steps)} on {self.device}")
             else:
-                tokens = torch.empty((B, steps), dtype=torch.int32, device=self.device)
-                scores = torch.empty((B, steps), dtype=torch.float32, device=self.device)
+                both = torch.empty((2, B, steps), dtype=torch.int32, device=self.device)      # one allocation: tokens | score bits
+                tokens, scores = both[0], both[1].view(torch.float32)
             call["out"] = (tokens, scores)
             rc = self._lib.rv_beam_search_submit_dev(self._h, pr, pe, B, Tr, Te, W, L, ctypes.c_void_p(tokens.data_ptr()),
                                                      ctypes.c_void_p(scores.data_ptr()), ctypes.byref(t))
