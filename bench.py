@@ -300,38 +300,47 @@ def main():
     if depth:
         bc.set_async_depth(depth)
     bc.set_option("wide_recurrence", {"mx": 1, "fma": 0, "auto": -1}[args.recurrence])
-    slabs_of_step = [(d_raw[a:a + B], d_ev[a:a + B]) for a in range(lo, hi, B)] if (not dist_path or os.environ.get("RV_BENCH_PLAIN_STEPS")) else None
+    plain_steps = not dist_path or bool(os.environ.get("RV_BENCH_PLAIN_STEPS"))     # (diagnostic switch: process group up, steps without it)
+    cut = lambda g: [(g[0][a:a + B], g[1][a:a + B]) for a in range(lo, hi, B)]      # this rank's slabs of one global batch
+    # the warm-up runs on DISTINCT global batches (other seeds), so that every slab context's buffers hold something else when the timed
+    # region starts: a result read from the wrong context or a stale buffer cannot pass the check after the timed region
+    warm_batches = []
+    for i in range(3):
+        rw, ew, _ = rv.synthetic.make_slab(n_global, T_r, T_e, seed=7001 + i)
+        warm_batches.append((torch.from_numpy(rw).to(dev), torch.from_numpy(ew).to(dev)))
 
-    def run_steps(k):
-        """k steps; returns (last result, per-step completion times).  depth > 0: the steps' slabs stream through the asynchronous
-        calls, `depth` in flight; a step is complete when its last slab is collected.  N > 1: the shipped multi-GPU path, shard ->
-        decode -> ONE all-gather (RCCL over xGMI) per step, the next step's shard submitted before this one is gathered."""
-        out, stamps = None, []
-        if dist_path and not os.environ.get("RV_BENCH_PLAIN_STEPS"):     # (diagnostic switch: process group up, steps without it)
-            if depth and not args.gather_per_step:     # every rank streams its shards of all k steps, ONE all-gather at the end
-                outs = rv.dist.sharded_beam_search_many(bc, [(d_raw, d_ev)] * k, W, L, slab=B, reuse_buffers=True)
-                out = outs[-1]
+    def run_steps(k, batches=None, gather_per_step=args.gather_per_step):
+        """k steps; returns (the results of every step, per-step completion times).  depth > 0: the steps' slabs stream through the
+        asynchronous calls, `depth` in flight; a step is complete when its last slab is collected.  N > 1: the shipped multi-GPU path,
+        shard -> decode -> ONE all-gather (RCCL over xGMI) at the end of the steps (or one per step, the next step's shard submitted
+        before this one is gathered).  `batches`: the global batches the steps cycle through (default: the bench batch, every step)."""
+        batches = batches or [(d_raw, d_ev)]
+        glob = [batches[i % len(batches)] for i in range(k)]
+        outs, stamps = [], []
+        if not plain_steps:
+            if depth and not gather_per_step:     # every rank streams its shards of all k steps, ONE all-gather at the end
+                outs = list(rv.dist.sharded_beam_search_many(bc, glob, W, L, slab=B, reuse_buffers=True))
                 stamps = [time.perf_counter()] * k
             elif depth:
-                for out in rv.dist.sharded_beam_search_stream(bc, ((d_raw, d_ev) for _ in range(k)), W, L, slab=B):
-                    stamps.append(time.perf_counter())
+                for out in rv.dist.sharded_beam_search_stream(bc, iter(glob), W, L, slab=B):
+                    outs.append(out); stamps.append(time.perf_counter())
             else:
-                for _ in range(k):
-                    out = rv.dist.sharded_beam_search(bc, d_raw, d_ev, W, L, slab=B)
+                for g in glob:
+                    outs.append(rv.dist.sharded_beam_search(bc, g[0], g[1], W, L, slab=B))
                     stamps.append(time.perf_counter())
-            return out, stamps
+            return outs, stamps
         if depth:
-            n, per = 0, len(slabs_of_step)
-            for out in bc.beam_search_stream((x for _ in range(k) for x in slabs_of_step), W, L):
+            n, per = 0, max(len(cut(glob[0])), 1)
+            for out in bc.beam_search_stream((x for g in glob for x in cut(g)), W, L):
                 n += 1
                 if n % per == 0:
-                    stamps.append(time.perf_counter())
-            return out, stamps
-        for _ in range(k):
-            for x in slabs_of_step:
+                    outs.append(out); stamps.append(time.perf_counter())
+            return outs, stamps
+        for g in glob:
+            for x in cut(g):
                 out = bc.beam_search_prediction(x, beam_width=W, max_output_len=L)
-            stamps.append(time.perf_counter())
-        return out, stamps
+            outs.append(out); stamps.append(time.perf_counter())
+        return outs, stamps
 
     def fence():
         if dist_path:
@@ -350,18 +359,23 @@ def main():
         _g = torch.zeros((world, 8), dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_gather_into_tensor(_g, _g[rank:rank + 1].clone())
         del _g
-    run_steps(max(args.warmup, 1))         # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
+    run_steps(max(args.warmup, 1), warm_batches)   # (>=1: contexts, graph capture and event pools are built here, not in the timed region)
     for _ in range(int(os.environ.get("RV_BENCH_PRERUN", "0"))):      # diagnostic: whole untimed passes of the K steps first
         run_steps(args.steps)
+    if plain_steps and depth:              # the K result pairs the timed region keeps (for the check after it): their allocator blocks exist already
+        _pre = [torch.empty((2, B, max(L - 1, 0)), dtype=torch.int32, device=dev) for _ in range(args.steps * max(len(cut((d_raw, d_ev))), 1))]
+        del _pre
     bc.reset_profile()
     fence()
     if os.environ.get("RV_BENCH_GAP_MS"):          # diagnostic: an idle gap between the warm-up and the timed region
         time.sleep(float(os.environ["RV_BENCH_GAP_MS"]) * 1e-3)
     t0 = time.perf_counter()
-    (tok, sc), stamps = run_steps(args.steps)
+    timed_outs, stamps = run_steps(args.steps)
     t_run = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
+    # `reuse_output_buffers` / the reused gather buffers: results are views that the next call with the same shapes overwrites -> copy now
+    timed_outs = [(t.clone(), s_.clone()) for t, s_ in timed_outs]
     if os.environ.get("RV_BENCH_VERBOSE"):
         print(f"timed region: run_steps {t_run * 1e3:.3f} ms, closing fence {(dt - t_run) * 1e3:.3f} ms", file=sys.stderr)
     gc.enable()
@@ -384,10 +398,18 @@ def main():
         torch.cuda.synchronize()
         steady = (time.perf_counter() - ts) / n_ss
         gc.enable()
+    gather_step_ms = None
+    if not plain_steps and depth and not args.gather_per_step and not args.no_extras:     # every rank takes part: collectives inside
+        run_steps(max(args.warmup, 1), None, True)
+        fence()
+        ts = time.perf_counter()
+        run_steps(args.steps, None, True)
+        fence()
+        gather_step_ms = (time.perf_counter() - ts) / args.steps
     slabs_per_step = -(-(hi - lo) // B)            # this rank's launches of each kernel per step
     x0 = (d_raw[lo:lo + B], d_ev[lo:lo + B])       # this rank's first slab: what the untimed per-kernel passes run on
     Bk = int(x0[0].shape[0])
-    chunk_steps, prof_iso, sync_ms = None, {}, None
+    chunk_steps, prof_iso, sync_ms, sync_auto_ms, verified = None, {}, None, None, None
     # which recurrence form the timed region ran (auto: the matrix form when more than 256 chunks are in flight together)
     wide_used = {"mx": True, "fma": False, "auto": Bk * max(depth, 1) > 256}[args.recurrence]
     if rank == 0:
@@ -402,19 +424,57 @@ def main():
         S = int(tk0.shape[1])
         if not args.per_step_decode:
             chunk_steps = bc.get_tensor("chunk_steps").astype(int)
-        bc.set_option("wide_recurrence", -1)
         bc.set_option("profile", 0)
-        if world == 1:                 # the synchronous call's rate, beside the headline (untimed extra; recurrence form chosen per call)
-            gc.collect(); gc.disable()
-            for _ in range(3):
-                bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(20):
-                bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
-            torch.cuda.synchronize()
-            sync_ms = (time.perf_counter() - ts) / 20 * 1e3
-            gc.enable()
+        # ---- the check of what the timed region returned (untimed): EVERY timed step's tokens and scores against a synchronous call on
+        # the same input -- byte for byte when the recurrence form is fixed (mx / fma), to f32 rounding with `auto` (the synchronous call
+        # then picks the other form).  N > 1: the gathered global batch against this rank decoding all of it, slab by slab.
+        want_t, want_s = [], []
+        for a in range(0, n_global, B):
+            t_, s_ = bc.beam_search_prediction((d_raw[a:a + B], d_ev[a:a + B]), beam_width=W, max_output_len=L)
+            want_t.append(t_.clone()); want_s.append(s_.clone())
+        S_all = max(int(t_.shape[1]) for t_ in want_t)
+        end_tok = int(bc.output_end_token)
+        def widen(t_, s_):      # a slab that stopped before the global batch's longest one: what the slab-wide loop would have emitted
+            if t_.shape[1] == S_all or t_.shape[1] == 0:
+                return t_, s_
+            pad = S_all - t_.shape[1]
+            return (torch.cat([t_, torch.full((t_.shape[0], pad), end_tok, dtype=t_.dtype, device=t_.device)], 1),
+                    torch.cat([s_, s_[:, -1:].expand(-1, pad)], 1))
+        if plain_steps:
+            want = (want_t[-1], want_s[-1]) if len(want_t) == 1 else None
+        else:
+            ws = [widen(t_, s_) for t_, s_ in zip(want_t, want_s)]
+            want = (torch.cat([w_[0] for w_ in ws], 0), torch.cat([w_[1] for w_ in ws], 0))
+        n_ok, exact = 0, args.recurrence != "auto"
+        for t_, s_ in timed_outs:
+            w_t, w_s = want if want is not None else (want_t[-1], want_s[-1])       # (plain steps keep the step's LAST slab)
+            w_t, w_s = w_t.to(t_.device), w_s.to(s_.device)
+            if tuple(t_.shape) != tuple(w_t.shape):
+                continue
+            if exact:
+                n_ok += int(torch.equal(t_, w_t) and torch.equal(s_.view(torch.int32), w_s.view(torch.int32)))
+            else:
+                rows = (t_ == w_t).all(dim=1)
+                n_ok += int(rows.float().mean().item() >= 0.98 and (not rows.any() or (s_[rows] - w_s[rows]).abs().max().item() < 1e-4))
+        verified = {"ok": n_ok == len(timed_outs) and len(timed_outs) == args.steps, "steps_checked": len(timed_outs), "steps_equal": n_ok,
+                    "how": ("tokens and score bits of every timed step == a synchronous call on the same input" if exact else
+                            "every timed step vs a synchronous call (other recurrence form): >= 98 % rows token-identical, their scores within 1e-4")
+                           + "; the warm-up ran on other inputs, so every context held different data when the timed region started"}
+        if world == 1:                 # the synchronous call's rate, beside the headline (untimed extras): the headline's recurrence form,
+            def time_sync(n=20):       # and the per-call choice of form (option wide_recurrence = -1)
+                gc.collect(); gc.disable()
+                for _ in range(3):
+                    bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(n):
+                    bc.beam_search_prediction(x0, beam_width=W, max_output_len=L)
+                torch.cuda.synchronize()
+                gc.enable()
+                return (time.perf_counter() - ts) / n * 1e3
+            sync_ms = time_sync()
+            bc.set_option("wide_recurrence", -1)
+            sync_auto_ms = time_sync()
     if os.environ.get("RV_BENCH_VERBOSE"):
         print("per-step ms:", " ".join(f"{x*1e3:.2f}" for x in per_step), file=sys.stderr)
 
@@ -503,26 +563,27 @@ def main():
             return r
 
         name = order[0]
-        if name in prof_dec:            # the decode launch is timed inside the timed region (profile 3), other slabs in flight around it
-            ms, n = prof_dec[name]
-            roof = roof_of(name, ms / max(n, 1), n, f"hipEvents inside the timed region, {max(depth, 1)} slab(s) in flight")
-        else:
-            roof = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass, the launch alone on the chip")
+        # `roofline` = the dominant kernel's launch ALONE on the chip (hipEvents on the library's stream around it, an untimed pass of
+        # synchronous calls of the timed region's kernels right after the timed region): a kernel figure, and the contract's cross-check
+        # -- the dominant kernel's time per step <= ms_per_step -- holds for it.  The same launch timed INSIDE the timed region
+        # (profile 3) spans the other slabs' kernels that share the chip with it, so it is reported as a span, not as a roofline.
+        roof = roof_of(name, per_slab[name], 10, "hipEvents on the library's stream around the launch, the launch alone on the chip "
+                                                  "(untimed pass of 10 synchronous calls after the timed region)")
         roof["share_of_cu_time"] = round(cu_ms[name] / sum(cu_ms.values()), 3)
         if roof["bound"] == "mfma" and "peak_note" not in roof:
             roof["peak_note"] = PEAK_NOTE
-        roof_iso = roof_of(name, per_slab[name], 10, "hipEvents, untimed pass of synchronous calls, the launch alone on the chip")
-        if depth and name in prof_dec and roof.get("frac") and roof_iso.get("frac"):
-            # with D slabs in flight the launch's span covers the other slabs' kernels that share the chip with it: `frac` (the
-            # contract's flops / live span) then says how long a launch waits, not how well the kernel runs.  Two readings beside it:
-            # the launch alone on the chip, and the timed region's step time x this kernel's share of the slab's CU-time
-            roof["frac_alone"] = roof_iso["frac"]
+        if name in prof_dec and roof.get("flops_per_launch"):
+            ms, n = prof_dec[name]
+            span = ms / max(n, 1)
+            roof["span_ms_in_stream"] = round(span, 5)
+            roof["launches_in_stream"] = n
+            roof["frac_live_span"] = round(roof["flops_per_launch"] / (span * 1e-3) / 1e12 / roof["peak"], 4)
             chip_ms = (dt / args.steps) * 1e3 / max(slabs_per_step, 1) * roof["share_of_cu_time"]
             roof["chip_time_ms_per_launch"] = round(chip_ms, 5)
-            roof["frac_chip_time"] = round(roof["flops_per_launch"] / (chip_ms * 1e-3) / 1e12 / roof["peak"], 4) if roof.get("flops_per_launch") else None
-            roof["span_note"] = (f"avg_launch_ms is the live span with {depth} slabs in flight (other slabs' kernels run on the same CUs "
-                                 "inside it); frac_alone = the launch alone on the chip (roofline_isolated); frac_chip_time = "
-                                 "FLOPs / (timed ms per slab x share_of_cu_time)")
+            roof["frac_chip_time"] = round(roof["flops_per_launch"] / (chip_ms * 1e-3) / 1e12 / roof["peak"], 4)
+            roof["span_note"] = (f"span_ms_in_stream = hipEvents around the same launch INSIDE the timed region, {max(depth, 1)} slab(s) in flight: "
+                                 "other slabs' kernels run on the same CUs inside it (frac_live_span prices queueing, not the kernel); "
+                                 "frac_chip_time = FLOPs / (timed ms per slab x share_of_cu_time): what the kernel costs the chip in the stream")
         top2 = [roof_of(k, per_slab[k], 10, "hipEvents, untimed pass, the launch alone on the chip") for k in order[1:3]
                 if algorithmic_flops(k, Bk, T_r, T_e, W, S)]
         for r, k in zip(top2, [k for k in order[1:3] if algorithmic_flops(k, Bk, T_r, T_e, W, S)]):
@@ -558,7 +619,6 @@ def main():
                        "parallelism": f"chunk-shard x{world}" + ((" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if (args.gather_per_step or not depth) else
                                                                        " + ONE RCCL all-gather at the end of the steps (dist.sharded_beam_search_many)") if dist_path else "")},
             "roofline": roof,
-            "roofline_isolated": roof_iso,
             "roofline_top2": top2,
             "roofline_path": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": PEAK_F32_TFLOPS * world, "unit": "TFLOP/s",
                               "frac": round(tf_exec / (PEAK_F32_TFLOPS * world), 4),
@@ -569,16 +629,26 @@ def main():
             "kernel_cu_ms_per_slab": {k: round(v, 4) for k, v in sorted(cu_ms.items())},
             "decode_kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 5) for k, v in sorted(dec.items())},
             # (streamed steps complete in bursts: these are intervals between step COMPLETIONS, not step latencies)
-            "step_completion_interval_ms_min_med_max": [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))],
+            # (one gather for all K steps: every step completes at the same instant -- no intervals to report)
+            "step_completion_interval_ms_min_med_max": (None if (not plain_steps and depth and not args.gather_per_step) else
+                                                        [round(x * 1e3, 3) for x in (min(per_step), sorted(per_step)[len(per_step) // 2], max(per_step))]),
+            "verified": verified,
         }
+        if gather_step_ms is not None:
+            out["gather_per_step"] = {"ms_per_step": round(gather_step_ms * 1e3, 4), "chunks_per_s": round(n_global / gather_step_ms, 1),
+                                      "note": "untimed extra: the same steps with one all-gather per step (dist.sharded_beam_search_stream) -- the protocol of "
+                                              "earlier rounds' multi-GPU lines; the headline gathers ONCE for all K steps (dist.sharded_beam_search_many)"}
         if steady is not None:
             out["steady_state"] = {"ms_per_step": round(steady * 1e3, 4), "chunks_per_s": round(n_global / steady, 1),
                                    "note": f"untimed extra: {4 * max(args.steps, 10)} more steps of the same stream right after another {max(args.steps, 10)}, "
                                            "fill and drain amortised, clocks settled"}
         if sync_ms is not None:
             out["synchronous"] = {"ms_per_step": round(sync_ms, 4), "chunks_per_s": round(Bk / sync_ms * 1e3, 1),
-                                  "note": "rv_beam_search_dev, one slab at a time, wide_recurrence = -1 (per-call choice: the packed-FMA kernels "
-                                          "for one isolated slab of <= 256 chunks); untimed extra: 20 calls after the timed region"}
+                                  "note": "rv_beam_search_dev, one slab at a time, the SAME kernels as the headline (recurrence form "
+                                          f"'{args.recurrence}'); untimed extra: 20 calls after the timed region"}
+            out["synchronous_auto"] = {"ms_per_step": round(sync_auto_ms, 4), "chunks_per_s": round(Bk / sync_auto_ms * 1e3, 1),
+                                       "note": "the same with wide_recurrence = -1 (form chosen per call: the packed-FMA recurrences for one isolated "
+                                               "slab of <= 256 chunks -- other kernels than the headline's; results agree to f32 rounding)"}
     bc.close()
     if rank == 0:
         if world == 1 and not args.no_extras:      # sub-lines outside the timed region (own handles)

@@ -9,9 +9,24 @@
  * success and a negative RV_E* code on failure; the message is available through
  * rv_last_error().  Nothing throws across the boundary.  A handle is bound to ONE device and
  * is NOT thread-safe (the reference is single-threaded and synchronous:
- * ravvent_performance_evaluator.py:51-55); use one handle per GPU / per process.  All calls
- * are synchronous: results are complete when the call returns, so a caller's wall-clock
- * timers mean what they mean around the reference's methods.
+ * ravvent_performance_evaluator.py:51-55); use one handle per GPU / per process.
+ *
+ * Synchronous calls -- rv_beam_search, rv_beam_search_dev, rv_beam_search_calls, rv_greedy_search,
+ * rv_greedy_search_dev, rv_load_weights, rv_get_tensor: results are complete when the call
+ * returns, so a caller's wall-clock timers mean what they mean around the reference's methods.
+ * Asynchronous calls -- rv_beam_search_submit, _submit_dev, _submit_calls: they return once the
+ * slab is queued; the matching rv_beam_search_collect* waits for it.  A synchronous call may be
+ * made while tickets are in flight: it runs on an idle slab context of the handle (its own when
+ * that one is idle) and fails with RV_ESTATE, touching nothing, when every context holds an
+ * uncollected ticket.  rv_get_tensor and the debug-tap options refer to the handle's OWN context:
+ * with taps on, a synchronous call needs that context idle.
+ *
+ * Hardware queues: every slab context is one HIP stream, and the HIP runtime multiplexes a
+ * process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says
+ * otherwise when the runtime starts, i.e. at the process's first HIP call).  Loading this
+ * library sets GPU_MAX_HW_QUEUES=16 if the variable is unset (RAVVENT_KEEP_ENV=1 opts out): load
+ * it before the first HIP call, or export the variable yourself.  rv_set_option("async_depth", n)
+ * returns the warning RV_WQUEUES when n exceeds the setting it finds.
  *
  * Host-buffer entry points copy inputs H2D / outputs D2H themselves.  The *_dev variants
  * take device addresses valid on the handle's device (e.g. torch tensor data_ptr()) and move
@@ -30,6 +45,8 @@ extern "C" {
 #define RV_ABI_VERSION 1
 
 enum { RV_OK = 0, RV_EINVAL = -1, RV_ENOMEM = -2, RV_EHIP = -3, RV_ESTATE = -4, RV_EUNSUPPORTED = -5 };
+/* Positive codes are warnings: the call took effect, rv_last_error() says what to look at. */
+enum { RV_WQUEUES = 1 };   /* rv_set_option("async_depth", n): n exceeds the HIP runtime's hardware queues (GPU_MAX_HW_QUEUES) */
 enum { RV_MODE_RAW = 0, RV_MODE_EVENT = 1, RV_MODE_JOINT = 2 };      /* input_data_type, basecaller.py:180-185 */
 enum { RV_ATT_LUONG = 0, RV_ATT_BAHDANAU = 1 };                       /* basecaller.py:131-134 */
 
@@ -100,7 +117,8 @@ int rv_beam_search_calls(rv_handle h, const float* raw, const float* event, int3
  * ravvent_performance_evaluator.py:51-55).  The handle owns "async_depth" slab contexts (own stream and buffers, one set of
  * weights); rv_beam_search_submit* queues a slab's whole path on an idle context and returns a ticket without waiting for the
  * GPU, rv_beam_search_collect* waits for that slab and hands out its results, which are byte-identical to the synchronous
- * call's.  Up to async_depth slabs are in flight: slab k+1's encoders run beside the tail of slab k's decode (chunks leave the
+ * call's (with option "wide_recurrence" at 1, the default, or 0; at -1 the recurrence form is chosen per call from the slabs in flight,
+ * and the two forms agree to f32 rounding only).  Up to async_depth slabs are in flight: slab k+1's encoders run beside the tail of slab k's decode (chunks leave the
  * decode as their beams finish), and with several slabs in flight the encoder recurrences switch to 16 chunks per workgroup on
  * the matrix pipe (option "wide_recurrence").  Tickets may be collected in any order; submit fails with RV_ESTATE when every
  * context holds an uncollected call.  Same single-thread rule as the rest of the handle.
@@ -124,24 +142,28 @@ int rv_greedy_search(rv_handle h, const float* raw, const float* event, int32_t 
 int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, int32_t B, int32_t T_r,
                          int32_t T_e, int32_t L, int32_t* d_tokens, float* d_logits, int32_t* S_out);
 
-/* Options: "debug_taps" (0/1: keep per-step logits/alignments for rv_get_tensor),
- *          "use_graph"  (0/1: replay the decode loop from a captured hipGraph),
- *          "decode_split" (1..4, default 1: beam-search decode of one slab runs as that many
+/* Options.  The DEFAULT path is: matrix-pipe recurrences ("wide_recurrence" 1) + split-f16 GEMMs + the one-launch persistent decode with
+ * attention and cell product on the matrix pipe ("persistent_decode", "matrix_attention", "matrix_cell" 1).  Options marked [fma form] only
+ * act with "wide_recurrence" 0 (or -1 when it picks that form); options marked [per-step decode] only with "persistent_decode" 0, debug
+ * taps, or a configuration the persistent decode does not cover (more than two decoder cells; Bahdanau with two cells; beam > 5 with two cells).
+ *          "debug_taps" (0/1: keep per-step logits/alignments for rv_get_tensor),
+ *          "use_graph"  (0/1 [per-step decode]: replay the decode loop from a captured hipGraph),
+ *          "decode_split" (1..4, default 1 [per-step decode]: beam-search decode of one slab runs as that many
  *                       concurrent sub-slabs; results are identical),
- *          "attend_threads" (0 auto | 256 | 512: workgroup size of the single-pass attend; auto uses
+ *          "attend_threads" (0 auto | 256 | 512 [per-step decode]: workgroup size of the single-pass attend; auto uses
  *                       256 (two workgroups per CU) for slabs larger than the CU count),
- *          "flash_attend" (0/1, default 1: single-pass Luong attention over values only;
+ *          "flash_attend" (0/1, default 1 [per-step decode]: single-pass Luong attention over values only;
  *                       0 = two-pass keys-then-values dataflow of the reference),
- *          "concurrent_encoders" (0/1, default 1: in joint mode the event encoder runs on a side stream under the
+ *          "concurrent_encoders" (0/1, default 1 [fma form, with "fused_projection" 0]: in joint mode the event encoder runs on a side stream under the
  *                       raw encoder's input-projection GEMM; results are identical),
- *          "fused_projection" (0/1, default 1: encoder layers >= 1 compute their input projection inside the
+ *          "fused_projection" (0/1, default 1 [fma form]: encoder layers >= 1 compute their input projection inside the
  *                       recurrence kernel, on MFMA waves of the same workgroup; 0 = separate GEMM launch + pre-projected
  *                       tensor; results agree to fp32 rounding),
- *          "split_projection" (0/1/2, default 2: the fused projection runs on 16-bit MFMAs with both operands cut into parts
+ *          "split_projection" (0/1/2, default 2 [fma form for the encoder; 0 also moves the memory projection to f32 MFMAs on every path]: the fused projection runs on 16-bit MFMAs with both operands cut into parts
  *                       whose products are exact in f32.  2 = two f16 parts of the scaled operands (2^14 x, and W scaled per
  *                       column by a power of two), three products: operands held to 2^-23, what f32 holds; 1 = three bf16
  *                       parts, six products; 0 = v_mfma_f32_16x16x4_f32 on the f32 operands.  Results agree to f32 rounding),
- *          "tail_wave"  (0/1, default 1: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
+ *          "tail_wave"  (0/1, default 1 [fma form]: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
  *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
  *                       agree to fp32 rounding),
  *          "wide_recurrence" (1/0/-1, default 1: the encoder recurrences as ONE split-f16 MFMA product per step for 16 chunks of a
@@ -153,7 +175,8 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       the lower latency for ONE isolated slab of <= 256 chunks (C3 shape: 1.40 vs 1.86 ms).  -1 = choose per call
  *                       by that rule -- fastest, but the two forms agree to f32 rounding only, so results then depend on the slab
  *                       size; with 1 or 0 a chunk's result never depends on the slab or shard it travels in),
- *          "async_depth" (1..16, default 2: contexts the rv_beam_search_submit* calls rotate through),
+ *          "async_depth" (1..16, default 2: contexts the rv_beam_search_submit* calls rotate through; returns the warning RV_WQUEUES -- the
+ *                       option is set -- when the value exceeds GPU_MAX_HW_QUEUES as found in the environment, see "Hardware queues" above),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

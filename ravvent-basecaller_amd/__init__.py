@@ -12,8 +12,10 @@ import os as _os
 # streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with more contexts than queues some share a queue and serialise
 # (measured at the C3 shape: depth 4 -> 203 k chunks/s on 4 queues, 262 k on 8; depth 10 -> 278 k on 8 queues, 317 k on 16).  The
 # variable is read when the HIP runtime starts, i.e. at the process's first HIP call -- importing this package first is enough;
-# an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# an explicit setting wins, RAVVENT_KEEP_ENV=1 leaves the environment alone.  libravvent_hip.so does the same when it is loaded (C callers
+# never import this module), and rv_set_option("async_depth", n) returns the warning RV_WQUEUES when n exceeds the setting in force.
+if not _os.environ.get("RAVVENT_KEEP_ENV"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .config import RvConfig  # noqa: F401
 from . import data_loader, utils, weights, synthetic, dist, evaluator, event_detection, checkpoint  # noqa: F401

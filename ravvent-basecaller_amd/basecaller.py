@@ -139,7 +139,13 @@ class Basecaller:
         return flat
 
     def set_option(self, key: str, value: int):
-        self._check(self._lib.rv_set_option(self._h, key.encode(), int(value)), f"rv_set_option({key})")
+        rc = self._lib.rv_set_option(self._h, key.encode(), int(value))
+        if rc > 0:      # a warning code (include/ravvent_hip.h): the option took effect, the message says what to look at
+            import warnings
+            msg = self._lib.rv_last_error(self._h)
+            warnings.warn(f"rv_set_option({key}): {msg.decode() if msg else rc}", RuntimeWarning, stacklevel=2)
+            return
+        self._check(rc, f"rv_set_option({key})")
 
     # ------------------------------------------------------------------ input plumbing
     def _split_inputs(self, input_data):
