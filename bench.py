@@ -347,9 +347,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipEvents on the library's streams, live in the timed region, around the dominant launch (the decode) only:
-    # events around all ~12 launches of a slab cost 2.6 % of it; the other kernels are timed in an untimed pass below
-    bc.set_option("profile", 3)
+    # No profiling inside the timed region: two hipEvents per slab on the decode launch (option profile = 3, what rounds 2-3 timed with)
+    # cost the stream ~5 % (341 k against 358-373 k chunks/s at these settings, tools/graph_ab.py).  The dominant launch is timed alone
+    # (`roofline`) and inside an untimed copy of the stream (`span_ms_in_stream`) right after the timed region.
+    bc.set_option("profile", 0)
     import gc
     gc.collect(); gc.disable()             # before the warm-up: a collection between warm-up and timing idles the GPU (~50 ms)
     if dist_path and depth and not args.gather_per_step:   # the gather buffers of the K timed steps, sized ahead of time (a first-use
@@ -384,7 +385,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof_dec = bc.profile()            # decode launch(es), measured inside the timed region (all slabs in flight around them)
+    # the decode launch inside the stream (hipEvents on the library's stream around it, all slabs in flight around them): an untimed copy of
+    # the timed region with option profile = 3
+    prof_dec = {}
+    if plain_steps and depth:
+        bc.set_option("profile", 3)
+        run_steps(depth)
+        bc.reset_profile()
+        torch.cuda.synchronize()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        prof_dec = bc.profile()
+        bc.set_option("profile", 0)
     # Untimed extra, not `value`: the same stream of steps once the pipeline and the chip's clocks have settled.  The timed region above
     # starts from an idle GPU (the contract's synchronisation) and holds the pipeline's fill and drain; a service streams for minutes.
     steady = None
@@ -581,7 +593,7 @@ def main():
             chip_ms = (dt / args.steps) * 1e3 / max(slabs_per_step, 1) * roof["share_of_cu_time"]
             roof["chip_time_ms_per_launch"] = round(chip_ms, 5)
             roof["frac_chip_time"] = round(roof["flops_per_launch"] / (chip_ms * 1e-3) / 1e12 / roof["peak"], 4)
-            roof["span_note"] = (f"span_ms_in_stream = hipEvents around the same launch INSIDE the timed region, {max(depth, 1)} slab(s) in flight: "
+            roof["span_note"] = (f"span_ms_in_stream = hipEvents around the same launch inside an untimed copy of the timed region's stream, {max(depth, 1)} slab(s) in flight: "
                                  "other slabs' kernels run on the same CUs inside it (frac_live_span prices queueing, not the kernel); "
                                  "frac_chip_time = FLOPs / (timed ms per slab x share_of_cu_time): what the kernel costs the chip in the stream")
         top2 = [roof_of(k, per_slab[k], 10, "hipEvents, untimed pass, the launch alone on the chip") for k in order[1:3]

@@ -177,6 +177,11 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       size; with 1 or 0 a chunk's result never depends on the slab or shard it travels in),
  *          "async_depth" (1..16, default 2: contexts the rv_beam_search_submit* calls rotate through; returns the warning RV_WQUEUES -- the
  *                       option is set -- when the value exceeds GPU_MAX_HW_QUEUES as found in the environment, see "Hardware queues" above),
+ *          "slab_graph" (0/1, default 0: a call on the default path -- matrix-pipe recurrences, persistent decode, no profiling, no taps --
+ *                       replays as ONE hipGraphLaunch per slab (captured per slab context and call shape; the caller's input / output
+ *                       addresses reach the kernels through a table in mapped pinned memory) instead of ten kernel launches: half the
+ *                       host time per call (24 us against 46), but the replayed slabs stream 1.5-3 % slower on ROCm 7.2, so it is off
+ *                       unless a caller's host thread is the bottleneck; results are identical),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
  *                       debug taps runs its whole decode loop in ONE launch, one workgroup per chunk, the
  *                       chunk's attention memory resident in registers; 0 = per-step kernels in a hipGraph.

@@ -37,7 +37,12 @@ struct RecArgs {
   uint8_t* mask;         // matrix-pipe raw layer 0 only: also leaves utils.input_mask of its chunks at mask[b * mask_T + mask_t0 + t]
   int mask_T, mask_t0;   //   (the window is in LDS anyway; saves the slab a launch).  null = not asked for
   float pad;
+  const void* const* ptab;   // matrix-pipe raw layer 0 only: non-null = read the chunk inputs' address from ptab[RV_PTAB_RAW] instead of `x`
 };
+// Caller pointers of a slab call, read by the kernels through a small table in mapped pinned memory when the slab replays from a
+// hipGraph whose kernel arguments are frozen (ravvent_hip.cpp, option "slab_graph": one graph per slab context and call shape): the
+// only addresses that change from call to call.
+enum { RV_PTAB_RAW = 0, RV_PTAB_EVENT = 1, RV_PTAB_TOKENS = 2, RV_PTAB_OUT2 = 3, RV_PTAB_N = 4 };
 // F in {0,1,5}; rows_per_block in {1,2,4,8}
 void launch_lstm_rec(const RecArgs& a, int F, int rows_per_block, hipStream_t s);
 // layers >= 1 with x . W + b computed inside the kernel (MFMA waves beside the recurrence waves): a.x = [B,T,256] activations,
@@ -52,8 +57,9 @@ bool lstm_rec_mx_window_fits(int T);
 hipError_t configure_mx_kernels();
 // xw [rows,2,512] = x [rows,F] . W_dir [F,512] + b_dir for a layer-0 encoder with F = 5 (or 1) input features, both directions
 // mask != null: also writes utils.input_mask of the rows, mask[(r / T) * mask_T + mask_t0 + r % T] = all(x[r, :] != pad)
+// xtab != null: x is read from xtab[RV_PTAB_EVENT] (F == 5) / xtab[RV_PTAB_RAW] (F == 1) on the device instead
 void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw,
-                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s);
+                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s, const void* const* xtab = nullptr);
 hipError_t configure_rec_kernels();   // dynamic-LDS opt-in of the recurrence kernels; first error or hipSuccess
 // layer 0 stages its chunks' whole input windows in LDS: does a window of T steps x F features fit with that many rows per workgroup?
 bool lstm_rec_window_fits(int F, int rows_per_block, int T);
@@ -168,7 +174,8 @@ void launch_dec_attend(const DecState& d, const float* WmemT, bool flash, int st
 bool dec_persist_supported(const DecState& d);
 void launch_dec_persist(const DecState& d, const float* Wcat /*[256,512]*/, const float* Wtok /*[V,512]*/,
                         const float* bdec /*[512]*/, const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s);
-void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s);
+// ptab != null: the two output addresses are read from ptab[RV_PTAB_TOKENS] / ptab[RV_PTAB_OUT2] on the device instead
+void launch_dec_finalize(const DecState& d, int32_t* tokens /*[B,L-1]*/, float* scores_or_logits, hipStream_t s, const void* const* ptab = nullptr);
 struct DecParts { const int* nfin[4]; int B[4]; int n; int steps; int* S_dev; int* S_host; };
 void launch_dec_reduce_steps(const DecParts& p, hipStream_t s);   // S_dev[0] = max_g S_g, S_dev[1+g] = S_g
 

@@ -1815,9 +1815,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 
 // One 64-thread workgroup per chunk: the chunk's [S,W] ids/parents are staged in LDS so the
 // serial gather_tree back-trace runs on LDS latency, not on dependent global loads.
-__global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens, float* out2) {
+__global__ __launch_bounds__(64) void k_dec_finalize(DecState d, int32_t* tokens, float* out2, const void* const* ptab) {
   __shared__ int s_ids[64 * RV_MAX_BEAM], s_par[64 * RV_MAX_BEAM], s_tok[64];
   __shared__ int s_S;
+  if (ptab) {      // graph replay: this call's output addresses (the kernel arguments are the capture's)
+    tokens = static_cast<int32_t*>(const_cast<void*>(ptab[RV_PTAB_TOKENS]));
+    out2 = static_cast<float*>(const_cast<void*>(ptab[RV_PTAB_OUT2]));
+  }
   const int b = blockIdx.x, tid = threadIdx.x;
   const int steps = d.L - 1, W = d.W, V = d.V;
   // S: steps the reference loop runs for the WHOLE slab (until every row is finished); So: steps this
@@ -2045,6 +2049,6 @@ hipError_t configure_decode_kernels() {
   return first;
 }
 
-void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s) {
-  hipLaunchKernelGGL(k_dec_finalize, dim3(d.B), dim3(64), 0, s, d, tokens, out2);
+void launch_dec_finalize(const DecState& d, int32_t* tokens, float* out2, hipStream_t s, const void* const* ptab) {
+  hipLaunchKernelGGL(k_dec_finalize, dim3(d.B), dim3(64), 0, s, d, tokens, out2, ptab);
 }

@@ -59,11 +59,12 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     dss[tid] = dsg[tid];
     if (F == 1) {
       wxs[tid] = a.W[dir][tid]; wxs[RV_G + tid] = a.bias[dir][tid];
+      const float* xg = a.ptab ? static_cast<const float*>(a.ptab[RV_PTAB_RAW]) : a.x;     // (graph replay: the caller's address of this call)
       for (int r = 0; r < RV_MX_ROWS; ++r) {
         const int b = min(b0 + r, a.B - 1);
         const bool wm = a.mask && dir == 0 && b0 + r < a.B;     // utils.input_mask of the raw part (utils.py:26-32), once per chunk
         for (int i = tid; i < T; i += 512) {
-          const float v = a.x[(size_t)b * T + i];
+          const float v = xg[(size_t)b * T + i];
           xs[r * T + i] = v;
           if (wm) a.mask[(size_t)b * a.mask_T + a.mask_t0 + i] = v != a.pad ? 1 : 0;
         }
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 // x . W + b for a layer-0 encoder with a handful of input features (the event encoder: F = 5), both directions:
 // xw [B*T, 2, 512].  One thread = 4 gate columns of one row; HBM-bound on its output (4 KB per chunk-timestep).
 template <int F>
-__global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ x, int rows, const float* __restrict__ W0, const float* __restrict__ b0,
+__global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ x_arg, int rows, const float* __restrict__ W0, const float* __restrict__ b0,
                                                        const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ xw,
-                                                       uint8_t* __restrict__ mask, int T, int mask_T, int mask_t0, float pad) {
+                                                       uint8_t* __restrict__ mask, int T, int mask_T, int mask_t0, float pad, const void* const* xtab) {
+  const float* __restrict__ x = xtab ? static_cast<const float*>(xtab[F == 1 ? RV_PTAB_RAW : RV_PTAB_EVENT]) : x_arg;
   const int c4 = threadIdx.x & 127, dir = threadIdx.x >> 7;
   const float* W = dir ? W1 : W0;
   const float* b = dir ? b1 : b0;
@@ -222,8 +224,8 @@ void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s) {
 }
 
 void launch_inproj_small(const float* x, int rows, int F, const float* W0, const float* b0, const float* W1, const float* b1, float* xw,
-                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s) {
+                         uint8_t* mask, int T, int mask_T, int mask_t0, float pad, hipStream_t s, const void* const* xtab) {
   const int grid = rows < 4096 ? rows : 4096;
-  if (F == 5) hipLaunchKernelGGL((k_inproj_small<5>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad);
-  else hipLaunchKernelGGL((k_inproj_small<1>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad);
+  if (F == 5) hipLaunchKernelGGL((k_inproj_small<5>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad, xtab);
+  else hipLaunchKernelGGL((k_inproj_small<1>), dim3(grid), dim3(256), 0, s, x, rows, W0, b0, W1, b1, xw, mask, T, mask_T, mask_t0, pad, xtab);
 }

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace {
@@ -29,6 +30,15 @@ struct GraphKey {
   int B, W, Tm, L, greedy, taps, split;
   bool operator<(const GraphKey& o) const {
     return std::tie(B, W, Tm, L, greedy, taps, split) < std::tie(o.B, o.W, o.Tm, o.L, o.greedy, o.taps, o.split);
+  }
+};
+
+// whole-slab graphs: everything of a call that ends up in a frozen kernel argument or decides which kernels run
+struct SlabKey {
+  int B, T_r, T_e, W, L, flags;             // flags: greedy | calls << 1 | host inputs << 2 | host outputs << 3
+  uint64_t lut;                             // the fused post-processing's letter table travels by value in a kernel argument
+  bool operator<(const SlabKey& o) const {
+    return std::tie(B, T_r, T_e, W, L, flags, lut) < std::tie(o.B, o.T_r, o.T_e, o.W, o.L, o.flags, o.lut);
   }
 };
 
@@ -115,6 +125,18 @@ struct RvContext {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> ev_pool;
   std::map<GraphKey, hipGraphExec_t> graphs;
+  // one hipGraph per slab context and call shape: the whole slab (ten launches on the default path) replays as ONE hipGraphLaunch.
+  // Every kernel argument is frozen at capture; the addresses that change from call to call (caller inputs and outputs) reach the
+  // kernels through a 4-entry table in mapped pinned memory (common.h: RV_PTAB_*), rewritten by the host before each replay
+  struct SlabGraph { hipGraphExec_t exec = nullptr; int lflash = 0, lkeys = 0, lpersist = 0, lsplit = 1, lW = 0; };
+  std::map<SlabKey, SlabGraph> slab_graphs;
+  const void** d_ptab = nullptr;
+  const void** pin_ptab = nullptr;
+  int opt_slab_graph = 0;                   // option "slab_graph": off by default -- measured (tools/graph_ab.py, C3, depth 10): a submit costs the host
+                                            // 22-27 us instead of 43-48, but the replayed slabs stream 1.5-3 % SLOWER (354-361 k against 361-370 k chunks/s
+                                            // settled; the runtime's per-node barrier packets), and the host is not what bounds the stream
+  int opt_gen = 0;                          // (root) bumped by every rv_set_option / rv_load_weights: frozen arguments may have changed
+  int graph_gen = 0;                        // the opt_gen this context's slab graphs were captured under
 
   // last call
   int lB = 0, lW = 0, lTm = 0, lL = 0, lS = 0, lgreedy = 0, ltaps = 0;
@@ -281,7 +303,7 @@ bool wide_recurrence(const RvContext* h, int B, int T_r) {
 }
 
 void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s,
-                 int l_begin = 0, int l_end = 1 << 30) {
+                 int l_begin = 0, int l_end = 1 << 30, const void* const* ptab = nullptr) {
   const int depth = h->cfg.enc_depth;
   const int bt = pick_rows_per_block(B);
   for (int l = std::max(l_begin, 0); l < std::min(depth, l_end); ++l) {
@@ -309,6 +331,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         a.x = x;
         for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
         a.mask = h->mask; a.mask_T = Tm; a.mask_t0 = t_off; a.pad = h->cfg.padding_value;   // the layer-0 kernels leave the input mask too
+        a.ptab = ptab;
         Scope sc(h, "lstm_rec_raw_l0", s);
         launch_lstm_rec_mx(a, 1, s);
         continue;
@@ -316,7 +339,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       if (l == 0) {
         Scope sc(h, e == 0 ? "inproj_raw_l0" : "inproj_event_l0", s);
         launch_inproj_small(x, B * T, F, h->enc[e][0][0].W, h->enc[e][0][0].b, h->enc[e][0][1].W, h->enc[e][0][1].b, h->xw[e],
-                            h->mask, T, Tm, t_off, h->cfg.padding_value, s);
+                            h->mask, T, Tm, t_off, h->cfg.padding_value, s, ptab);
       } else {
         Scope sc(h, e == 0 ? "gemm_inproj_raw" : "gemm_inproj_event", s);
         launch_gemm_split_blocks(h->act[e][(l - 1) & 1], B * T, h->d_Wx16 + (size_t)(e * (depth - 1) + (l - 1)) * RV_WX16_SLOT, 4,
@@ -390,6 +413,18 @@ void launch_decode_steps(RvContext* h, const DecState& d, hipStream_t s, bool pr
 
 struct CallsOut { const uint8_t* lut; uint8_t* bases; int32_t* lengths; float* probs; };
 
+// Does this call take the one-launch persistent decode (if the kernel has an instantiation for it: dec_persist_supported)?
+bool persist_wanted(const RvContext* h, bool greedy, int W, int Tm) {
+  const RvConfig& c = h->cfg;
+  const int W_eff = greedy ? 1 : W;
+  return h->opt_persist && h->opt_flash && !h->opt_taps && c.dec_depth <= 2 &&
+         (c.attention == RV_ATT_LUONG || (c.attention == RV_ATT_BAHDANAU && c.dec_depth == 1)) &&
+         W_eff <= (c.dec_depth > 1 ? 5 : 8) && Tm <= 352;
+}
+
+int record_slab(RvContext* h, const float* xr, const float* xe, bool host_in, int B, int T_r, int T_e, int W, int L, bool greedy,
+                int32_t* tk, float* o2, bool dev_out, const uint8_t* lut, const void* const* ptab);
+
 // Everything of a call up to (not including) the wait for the stream: launches and the D2H copies into pinned staging.
 // dev_out: tokens / out2 are device pointers written by the finalize kernel; else the results wait in pinned memory for finish().
 // lut != nullptr: the fused post-processing (rv_beam_search_calls) instead of tokens / scores.
@@ -420,23 +455,73 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   if (B == 0 || L <= 1) { h->pend.trivial = true; return RV_OK; }
 
   hipStream_t s = h->stream;
-  const int Tm = T_r + T_e, V = c.vocab, steps = L - 1;
   const float *xr = raw, *xe = ev;
-  if (!dev_in) {   // host -> pinned staging (CPU memcpy) -> async H2D
-    if (use_raw) {
-      memcpy(h->pin_raw, raw, sizeof(float) * B * T_r);
-      HIPCHK(h, hipMemcpyAsync(h->d_raw, h->pin_raw, sizeof(float) * B * T_r, hipMemcpyHostToDevice, s)); xr = h->d_raw;
-    }
-    if (use_ev) {
-      memcpy(h->pin_ev, ev, sizeof(float) * B * T_e * 5);
-      HIPCHK(h, hipMemcpyAsync(h->d_ev, h->pin_ev, sizeof(float) * B * T_e * 5, hipMemcpyHostToDevice, s)); xe = h->d_ev;
-    }
+  if (!dev_in) {   // host -> pinned staging (CPU memcpy); the H2D copies are part of the slab's stream work (record_slab)
+    if (use_raw) { memcpy(h->pin_raw, raw, sizeof(float) * B * T_r); xr = h->d_raw; }
+    if (use_ev) { memcpy(h->pin_ev, ev, sizeof(float) * B * T_e * 5); xe = h->d_ev; }
   }
 
   h->lwide = wide_recurrence(h, B, T_r) ? 1 : 0;
   if ((!h->opt_fuse && c.enc_depth > 1) || h->lwide) {   // pre-projected tensors [max_batch, T_max, 2, 512] (unfused path, matrix-pipe recurrence), allocated on first use
     if (use_raw && c.enc_depth > 1 && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
     if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
+  }
+  int32_t* tk = (dev_out && tokens) ? tokens : h->out_tokens;
+  float* o2 = (dev_out && out2) ? out2 : h->out2;
+
+  // ---- one hipGraph per slab context and call shape (option "slab_graph"): the default path -- matrix-pipe recurrences + persistent
+  // decode, no profiling, no taps -- replays as ONE hipGraphLaunch instead of ten launches (a submit's host time is what the GPU waits
+  // for whenever the slabs in flight finish together).  All kernel arguments are frozen at capture; the caller's addresses of THIS
+  // call go through the pointer table (mapped pinned memory, written here, read by the kernels).
+  RvContext* root = h->parent ? h->parent : h;
+  if (h->graph_gen != root->opt_gen) {          // an option or the weights changed since the capture: frozen arguments may be stale
+    for (auto& kv : h->slab_graphs) hipGraphExecDestroy(kv.second.exec);
+    h->slab_graphs.clear();
+    h->graph_gen = root->opt_gen;
+  }
+  const bool graphable = root->opt_slab_graph && h->lwide && persist_wanted(h, greedy, W, T_r + T_e) && h->opt_profile == 0 && !h->opt_taps &&
+                         !h->opt_ptaps && !h->rec_ts && !h->dec_st.dbg_ts && h->d_ptab;
+  if (!graphable) return record_slab(h, xr, xe, !dev_in, B, T_r, T_e, W, L, greedy, tk, o2, dev_out, lut, nullptr);
+  h->pin_ptab[RV_PTAB_RAW] = xr; h->pin_ptab[RV_PTAB_EVENT] = xe; h->pin_ptab[RV_PTAB_TOKENS] = tk; h->pin_ptab[RV_PTAB_OUT2] = o2;
+  SlabKey key{B, T_r, T_e, W, L, (greedy ? 1 : 0) | (calls ? 2 : 0) | (dev_in ? 0 : 4) | (dev_out ? 0 : 8), 0};
+  if (calls) memcpy(&key.lut, lut, std::min<size_t>(sizeof key.lut, (size_t)c.vocab));
+  auto it = h->slab_graphs.find(key);
+  if (it == h->slab_graphs.end()) {
+    if (h->slab_graphs.size() >= 16) {          // bound the cache (callers with ever-changing slab shapes)
+      for (auto& kv : h->slab_graphs) hipGraphExecDestroy(kv.second.exec);
+      h->slab_graphs.clear();
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = record_slab(h, xr, xe, !dev_in, B, T_r, T_e, W, L, greedy, tk, o2, dev_out, lut, h->d_ptab);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);      // (always: the stream must leave capture mode whatever record_slab said)
+    if (rc != RV_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    HIPCHK(h, ce);
+    RvContext::SlabGraph g;
+    const hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    HIPCHK(h, ie);
+    g.lflash = h->lflash; g.lkeys = h->lkeys; g.lpersist = h->lpersist; g.lsplit = h->lsplit; g.lW = h->lW;
+    it = h->slab_graphs.emplace(key, g).first;
+  }
+  const RvContext::SlabGraph& g = it->second;
+  h->lflash = g.lflash; h->lkeys = g.lkeys; h->lpersist = g.lpersist; h->lsplit = g.lsplit; h->lW = g.lW;
+  HIPCHK(h, hipGraphLaunch(g.exec, s));
+  return RV_OK;
+}
+
+// The stream work of one slab, in order: input copies, encoders, memory set-up, decode, finalize, output copies.  `ptab` non-null =
+// the call is being captured into a slab graph: kernels that touch caller memory read its address from the table.
+int record_slab(RvContext* h, const float* xr, const float* xe, bool host_in, int B, int T_r, int T_e, int W, int L, bool greedy,
+                int32_t* tk, float* o2, bool dev_out, const uint8_t* lut, const void* const* ptab) {
+  const RvConfig& c = h->cfg;
+  const bool calls = lut != nullptr;
+  const bool use_raw = c.mode != RV_MODE_EVENT, use_ev = c.mode != RV_MODE_RAW;
+  hipStream_t s = h->stream;
+  const int Tm = T_r + T_e, V = c.vocab, steps = L - 1;
+  if (host_in) {   // pinned staging -> device
+    if (use_raw) HIPCHK(h, hipMemcpyAsync(h->d_raw, h->pin_raw, sizeof(float) * B * T_r, hipMemcpyHostToDevice, s));
+    if (use_ev) HIPCHK(h, hipMemcpyAsync(h->d_ev, h->pin_ev, sizeof(float) * B * T_e * 5, hipMemcpyHostToDevice, s));
   }
   // ---- _encode_input (basecaller.py:395-416)
   // The mask is first read by the memory set-up / the decode: it runs on a side stream beside the encoders instead of in front
@@ -468,8 +553,8 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
     HIPCHK(h, hipEventRecord(h->ev_join[0], sev));
     HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
   } else {
-    if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, s);
-    if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
+    if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, s, 0, 1 << 30, ptab);
+    if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 0, 1 << 30, ptab);
   }
 
   if (mask_aside) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[2], 0));
@@ -479,9 +564,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   const int W_eff = greedy ? 1 : W;
   h->lflash = (c.attention == RV_ATT_LUONG && h->opt_flash && W_eff <= 5) ? 1 : 0;   // wider beams: register budget -> two-pass
   // the persistent decode (decided below, once the decode state is set up) needs neither keys nor the per-step kernels
-  const bool persist_ok = h->opt_persist && h->opt_flash && !h->opt_taps && c.dec_depth <= 2 &&
-                          (c.attention == RV_ATT_LUONG || (c.attention == RV_ATT_BAHDANAU && c.dec_depth == 1)) &&
-                          W_eff <= (c.dec_depth > 1 ? 5 : 8) && Tm <= 352;
+  const bool persist_ok = persist_wanted(h, greedy, W, Tm);
   h->lkeys = ((!h->lflash && !persist_ok) || h->opt_taps) ? 1 : 0;
   if (h->lkeys) {
     GemmArgs g{};
@@ -619,14 +702,12 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
     if (rc != RV_OK) return rc;
   }
 
-  int32_t* tk = (dev_out && tokens) ? tokens : h->out_tokens;
-  float* o2 = (dev_out && out2) ? out2 : h->out2;
   {
     Scope sc(h, "dec_finalize");
     if (!h->lpersist) launch_dec_reduce_steps(parts, s);
     for (int g = 0; g < parts.n; ++g) {
       const size_t b0 = parts.n == 1 ? 0 : (size_t)B * g / parts.n;
-      launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s);
+      launch_dec_finalize(part[g], tk + b0 * steps, o2 + b0 * steps * (greedy ? V : 1), s, ptab);     // (ptab: persistent decode only, one part)
     }
   }
   // (S reaches the host through d.S_host: the finalize / reduce kernel stores it straight into the mapped pinned word)
@@ -768,6 +849,10 @@ int alloc_slab_buffers(RvContext* h) {
   HIPTRY(hipHostMalloc((void**)&h->pin_bases, B * L, hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_probs, B * L * sizeof(float), hipHostMallocDefault));
   HIPTRY(hipHostMalloc((void**)&h->pin_clen, B * sizeof(int), hipHostMallocDefault));
+  // the table lives in mapped pinned memory: the three kernels that need a caller address read it over the host link once per workgroup
+  // (a device copy refreshed by a memcpy node in front of the graph measured the same, and is one node more)
+  HIPTRY(hipHostMalloc((void**)&h->pin_ptab, sizeof(void*) * RV_PTAB_N, hipHostMallocMapped));
+  HIPTRY(hipHostGetDevicePointer((void**)&h->d_ptab, h->pin_ptab, 0));
 #undef TRY
 #undef HIPTRY
   return RV_OK;
@@ -890,12 +975,13 @@ void rv_destroy(rv_handle h) {
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : h->slab_graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) hipEventDestroy(e);
   for (int g = 0; g < 3; ++g) { if (h->side[g]) hipStreamDestroy(h->side[g]); if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->step_align) hipFree(h->step_align);
-  for (void* p : {(void*)h->pin_raw, (void*)h->pin_ev, (void*)h->pin_tok, (void*)h->pin_out2, (void*)h->pin_S, (void*)h->pin_bases, (void*)h->pin_probs, (void*)h->pin_clen}) if (p) hipHostFree(p);
+  for (void* p : {(void*)h->pin_raw, (void*)h->pin_ev, (void*)h->pin_tok, (void*)h->pin_out2, (void*)h->pin_S, (void*)h->pin_bases, (void*)h->pin_probs, (void*)h->pin_clen, (void*)h->pin_ptab}) if (p) hipHostFree(p);
   for (void* p : h->allocs) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -910,6 +996,7 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
   if (h->pend.busy) return fail(h, RV_ESTATE, "collect the calls in flight before loading weights");
   for (RvContext* k : h->kids) if (k->pend.busy) return fail(h, RV_ESTATE, "collect the calls in flight before loading weights");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->opt_gen++;                      // (weight-derived scalars travel by value in the decode's kernel arguments)
   HIPCHK(h, hipMemcpyAsync(h->d_w, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
   {   // derived layout for the decoder cell kernel: the input-kernel rows that multiply a dense input
       // (rows V.. of W_0; all of W_k for k >= 1) followed by U_k form a contiguous [256][512] matrix in
@@ -1270,7 +1357,9 @@ int rv_beam_search_collect_calls(rv_handle h, int32_t ticket, uint8_t* bases, in
 
 int rv_set_option(rv_handle h, const char* key, int32_t value) {
   if (!h || !key) return RV_EINVAL;
+  h->opt_gen++;                      // slab graphs captured under the old options are rebuilt on their next use
   if (!strcmp(key, "debug_taps")) h->opt_taps = value != 0;
+  else if (!strcmp(key, "slab_graph")) h->opt_slab_graph = value != 0;
   else if (!strcmp(key, "persist_taps")) h->opt_ptaps = value != 0;
   else if (!strcmp(key, "use_graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;

@@ -233,3 +233,52 @@ def test_matrix_pipe_recurrence_adversarial_recurrent_kernel(rv, oracle, Tr, Te,
     assert err[1] < TOL and err[0] < TOL, (err, twin)
     assert err[1] <= 2.0 * err[0] + 2e-6, (err, twin)
     bc.close()
+
+
+def test_slab_graph_replay_matches_launches(rv):
+    """Option slab_graph: a call on the default path replays as ONE hipGraphLaunch per slab context and call shape, with every kernel
+    argument frozen at capture and the caller's input / output addresses read through a table in mapped pinned memory.  Byte-identical
+    to the launch-by-launch form for device inputs at EVER-CHANGING addresses (a stale pointer would decode the wrong slab or write the
+    wrong tensor), host inputs, the fused post-processing, greedy search, several shapes through one handle, asynchronous and
+    synchronous calls; new weights and a changed option take effect (the frozen arguments hold weight-derived scalars)."""
+    import torch
+    from test_parity_gpu import _emitting_flat
+    B, T_r, T_e, W, L = 48, 120, 20, 5, 24
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L)
+    flat = _emitting_flat(rv, bc.cfg, seed=5)
+    bc.set_weights_flat(flat)
+    host = [rv.synthetic.make_slab(n, T_r, T_e, seed=300 + i)[:2] for i, n in enumerate((48, 48, 17, 48, 48, 17, 48, 1))]
+    ref = [tuple(a.numpy().copy() for a in bc.beam_search_prediction(x, W, L)) for x in host]
+    ref_calls = [bc.beam_search_call_arrays(x, W, L) for x in host]
+    ref_greedy = [tuple(a.numpy().copy() for a in bc.greedy_search_prediction(x, L)) for x in host[:3]]
+    bc.set_option("slab_graph", 1)
+    bc.set_async_depth(3)
+    for rep in range(3):       # rep 0 captures (per context and shape), later reps replay; fresh device tensors = fresh addresses every time
+        dev = [(torch.from_numpy(r.copy()).cuda(), torch.from_numpy(e.copy()).cuda()) for r, e in host]
+        pad = torch.empty(1000 * (rep + 1), device="cuda")        # (shifts the allocator's addresses between reps)
+        outs = list(bc.beam_search_stream(dev, W, L))
+        assert all(_same(o, r) for o, r in zip(outs, ref)), rep
+        outs = list(bc.beam_search_stream(host, W, L))
+        assert all(_same(o, r) for o, r in zip(outs, ref)), rep
+        for got, want in zip(bc.beam_search_stream(host, W, L, calls=True), ref_calls):
+            assert all(np.array_equal(g, w_) for g, w_ in zip(got, want)), rep
+        for x, r in zip(dev, ref):                               # synchronous calls replay too
+            assert _same(bc.beam_search_prediction(x, W, L), r), rep
+        for x, r in zip(host[:3], ref_greedy):
+            g, lg = bc.greedy_search_prediction(x, L)
+            assert (g.numpy() == r[0]).all() and np.array_equal(lg.numpy(), r[1]), rep
+        del pad
+    # an option that changes the kernels, then new weights: the captured graphs are rebuilt, not replayed stale
+    bc.set_option("matrix_cell", 0)
+    t0, s0 = bc.beam_search_prediction(host[0], W, L)
+    bc.set_option("slab_graph", 0)
+    t1, s1 = bc.beam_search_prediction(host[0], W, L)
+    assert (t0.numpy() == t1.numpy()).all() and np.array_equal(s0.numpy(), s1.numpy())
+    bc.set_option("matrix_cell", 1); bc.set_option("slab_graph", 1)
+    flat2 = _emitting_flat(rv, bc.cfg, seed=6)
+    bc.set_weights_flat(flat2)
+    t2, s2 = bc.beam_search_prediction(host[0], W, L)
+    bc.set_option("slab_graph", 0)
+    t3, s3 = bc.beam_search_prediction(host[0], W, L)
+    assert (t2.numpy() == t3.numpy()).all() and np.array_equal(s2.numpy(), s3.numpy()) and not np.array_equal(s2.numpy(), ref[0][1])
+    bc.close()

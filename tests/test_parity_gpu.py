@@ -504,11 +504,11 @@ def test_every_documented_option_is_accepted(rv):
     """rv_set_option: every key the header documents exists, an unknown key is an error (include/ravvent_hip.h)."""
     import re
     hdr = open(os.path.join(os.path.dirname(HERE), "include", "ravvent_hip.h")).read()
-    doc = hdr[hdr.index("/* Options:"):hdr.index("int rv_set_option")]
+    doc = hdr[hdr.index("/* Options."):hdr.index("int rv_set_option")]
     keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
     assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
             "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "matrix_attention", "matrix_cell", "profile",
-            "wide_recurrence", "async_depth"} <= keys
+            "wide_recurrence", "async_depth", "slab_graph"} <= keys
     bc, _ = _mk(rv)
     for k in sorted(keys):
         bc.set_option(k, 1 if k != "attend_threads" else 256)
