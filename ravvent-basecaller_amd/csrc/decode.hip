@@ -232,6 +232,13 @@ constexpr int ATT_THREADS = 512;
 #define RV_STAMP_W1(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 64 * RV_STAMP_WAVE && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 #define RV_STAMP(d, step, i) do { if ((d).dbg_ts && blockIdx.x == 0 && threadIdx.x == 0 && (step) == 3) (d).dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
 constexpr float LOG2E = 1.4426950408889634f;
+// Matrix-pipe forms of the persistent decode: the A operand of every product (query, alignments, [ctx' | h]) has the beams as rows,
+// at most 8 of an MFMA tile's 16.  Both f16 PARTS of a beam's value therefore ride in ONE tile -- beam w: high part in row
+// 4 (w % 4) + 2 (w / 4), low part in the row after it -- so a product is TWO MFMAs per k-step (the tile against the high and against the
+// low part of B) instead of three, and one LDS read per k-step instead of two: rows r, r + 1 of `. B_hi` and row r of `. B_lo` are the
+// three exact part products (row r + 1 of `. B_lo` is the low x low term, below 2^-22 of the product: it is simply added too).
+// C/D map of the 16x16 tile: lane (column l % 16, g = l / 16) holds rows 4 g + i, i = 0..3: registers 0 + 1 = beam g, 2 + 3 = beam g + 4.
+__host__ __device__ constexpr int mx_row(int w) { return 4 * (w & 3) + 2 * (w >> 2); }
 
 // Static LDS shared by both attend kernels: output layer, new cell states, beam bookkeeping.
 struct AttShared {
@@ -1148,14 +1155,14 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         {   // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
           const float sv = hh * 16384.f;
           const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-          _Float16* xq = xim + (((RV_U + u) >> 3) * 8 + w) * 8 + (u & 7);
-          xq[0] = hi; xq[2048] = lo;
+          _Float16* xq = xim + (((RV_U + u) >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
+          xq[0] = hi; xq[8] = lo;
         }
-        {   // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
+        {   // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
           const float sv = (hh * LOG2E) * 16384.f;
           const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-          _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 8 + w) * 8 + (u & 7);
-          qa[0] = hi; qa[1024] = lo;
+          _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
+          qa[0] = hi; qa[8] = lo;
         }
       }
     } else
@@ -1172,11 +1179,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
       if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
-      if constexpr (MX) {      // the score query as MFMA A fragments: [part][k-block u / 8][row w][u % 8] f16 of h log2(e) 2^14
+      if constexpr (MX) {      // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
         const float sv = (hh * LOG2E) * 16384.f;
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-        _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 8 + w) * 8 + (u & 7);
-        qa[0] = hi; qa[1024] = lo;
+        _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
+        qa[0] = hi; qa[8] = lo;
       }
     }
     __syncthreads();
@@ -1289,36 +1296,35 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 
     if constexpr (MX) {
       // ================= scores on the matrix pipe: rows = beams, columns = the 16 steps of a tile, K = 128 units.
-      //   C/D map: lane l holds column l % 16 and rows 4 g + i (g = l / 16).  Beam w sits in row 4 (w % 4) + w / 4, so that
-      //   register i = 0 holds beams 0-3 (one per 16-lane group, all 64 lanes busy) and i = 1 beams 4-7: the softmax below
-      //   touches W <= 4 ? 1 : 2 registers per tile, not 4.  A row of A only feeds its own row of C, so the unused rows of the
-      //   16-row tile read whatever slot their index aliases to, harmlessly.  LDS images keep 8 row slots, slot = beam.
+      //   C/D map: lane l holds column l % 16 and rows 4 g + i (g = l / 16).  Beam w sits in rows mx_row(w), + 1 (its high and its low
+      //   part: see mx_row), so that registers 0 + 1 hold beams 0-3 (one per 16-lane group, all 64 lanes busy) and 2 + 3 beams 4-7: the
+      //   softmax below touches W <= 4 ? 1 : 2 values per tile.  A row of A only feeds its own row of C, so the rows of absent beams
+      //   hold whatever the LDS image holds there, harmlessly.
       constexpr int NI = W > 4 ? 2 : 1;
       const int l16 = lane & 15, kq = lane >> 4;
-      const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;    // the beam whose row this lane feeds as an A operand
       float sc[NTT][NI];
       {
-        const _Float16* qa = reinterpret_cast<const _Float16*>(fold) + (kq * 8 + aslot) * 8;
+        const _Float16* qa = reinterpret_cast<const _Float16*>(fold) + (kq * 16 + l16) * 8;    // row l16 of k-block 4 ks + kq
+        // the tiles in turns (against the low, then against the high part of the keys): an MFMA accumulates onto a result that is NTT
+        // instructions old, not onto the one issued just before it
         f4v acc[NTT];
 #pragma unroll
         for (int c = 0; c < NTT; ++c) acc[c] = f4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                    // one k-step of the query at a time: 8 registers of A fragments live
-          const h8 ah = *reinterpret_cast<const h8*>(qa + ks * 256), al = *reinterpret_cast<const h8*>(qa + 1024 + ks * 256);
+        for (int ks = 0; ks < 4; ++ks) {                    // one k-step of the query at a time: 4 registers of A fragments live
+          const h8 a = *reinterpret_cast<const h8*>(qa + ks * 512);
 #pragma unroll
-          for (int c = 0; c < NTT; ++c) {
-            const h8 bh = __builtin_bit_cast(h8, kb[c][ks][0]), bl = __builtin_bit_cast(h8, kb[c][ks][1]);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
-          }
+          for (int c = 0; c < NTT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, kb[c][ks][1]), acc[c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NTT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, kb[c][ks][0]), acc[c], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int c = 0; c < NTT; ++c) {
           const bool live = (livebits >> c) & 1u;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) sc[c][i] = (live && kq + 4 * i < W) ? acc[c][i] * d.mx_kdescale : -INFINITY;
+          for (int i = 0; i < NI; ++i)
+            sc[c][i] = (live && kq + 4 * i < W) ? (acc[c][2 * i] + acc[c][2 * i + 1]) * d.mx_kdescale : -INFINITY;
         }
       }
       RV_STAMP(d, step, 4);
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         tl += dpp<0xB1>(tl); tl += dpp<0x4E>(tl); tl += dpp<0x141>(tl);
         // all-masked chunk: 0 / 0 = NaN like the reference
         const float rt = Mgl == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tl;
-        // alignments -> A fragments of the context product: [part][k-block t / 8][slot beam][t % 8] f16 of alpha 2^14 (in `part`,
+        // alignments -> A fragments of the context product: [k-block t / 8][row mx_row(beam) (+ 1: low part)][t % 8] f16 of alpha 2^14 (in `part`,
         // idle between the gates and the cell product at the end of the step)
         _Float16* aa = reinterpret_cast<_Float16*>(part);
 #pragma unroll
@@ -1368,8 +1374,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             if (t < 32 * NIT) {
               const float av = nanrow ? rr : sc[c][i] * f;
               const _Float16 hi = (_Float16)av, lo = (_Float16)(av - (float)hi);
-              _Float16* q = aa + ((t >> 3) * 8 + beam) * 8 + (t & 7);
-              q[0] = hi; q[NIT * 256] = lo;
+              _Float16* q = aa + ((t >> 3) * 16 + mx_row(beam)) * 8 + (t & 7);
+              q[0] = hi; q[8] = lo;
             }
           }
         }
@@ -1379,16 +1385,17 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       // ================= attention-layer context part = sum_t alpha_t U'_t on the matrix pipe: rows = beams, this wave's 16 units,
       //   K = the chunk's steps; the product is complete in one wave (no partial sums to merge)
       {
-        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 8 + aslot) * 8;
-        f4v acc = {0.f, 0.f, 0.f, 0.f};
+        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 16 + l16) * 8;
+        f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;           // against the high / the low part of U'
 #pragma unroll
         for (int ks = 0; ks < NIT; ++ks) {
-          const h8 ah = *reinterpret_cast<const h8*>(aa + ks * 256), al = *reinterpret_cast<const h8*>(aa + NIT * 256 + ks * 256);
-          const h8 bh = __builtin_bit_cast(h8, ub[ks][0]), bl = __builtin_bit_cast(h8, ub[ks][1]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+          const h8 a = *reinterpret_cast<const h8*>(aa + ks * 512);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][0]), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][1]), a1, 0, 0, 0);
         }
+        float acc[2];                                      // beams kq, kq + 4
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = (a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1]);
         RV_STAMP(d, step, 6);
         const int col = 16 * wv + l16;
 #pragma unroll
@@ -1399,8 +1406,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             if constexpr (MXC) {   // ctx' as A fragments of the cell product: k = col, ctx' . mx_uscale (= acc 2^-14, below 2^14) in two f16 parts
               const float sv = acc[i] * (1.0f / 16384.f);
               const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-              _Float16* xq = xim + ((col >> 3) * 8 + kq + 4 * i) * 8 + (col & 7);
-              xq[0] = hi; xq[2048] = lo;
+              _Float16* xq = xim + ((col >> 3) * 16 + mx_row(kq + 4 * i)) * 8 + (col & 7);
+              xq[0] = hi; xq[8] = lo;
             } else attT[col * WB + kq + 4 * i] = av;
           }
       }
@@ -1533,10 +1540,9 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       // h): no logits phase and no barrier in front of the beam step.
       if (wv == 0) {
         const int l16 = lane & 15, kq = lane >> 4;
-        const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;
-        const _Float16* xa = xim + (kq * 8 + aslot) * 8;
+        const _Float16* xa = xim + (kq * 16 + l16) * 8;
         const uint4* wl = reinterpret_cast<const uint4*>(dsm + L.wl16) + lane;
-        f4v acc = {0.f, 0.f, 0.f, 0.f};
+        f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           uint4 bh[4], bl[4];
@@ -1544,14 +1550,14 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           for (int i = 0; i < 4; ++i) { bh[i] = wl[(2 * (4 * half + i)) * 64]; bl[i] = wl[(2 * (4 * half + i) + 1) * 64]; }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int ks = 4 * half + i;
-            const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
-            const h8 wh = __builtin_bit_cast(h8, bh[i]), wlo = __builtin_bit_cast(h8, bl[i]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wlo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc, 0, 0, 0);
+            const h8 a = *reinterpret_cast<const h8*>(xa + (4 * half + i) * 512);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, bh[i]), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, bl[i]), a1, 0, 0, 0);
           }
         }
+        float acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = (a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1]);
         constexpr int NI = W > 4 ? 2 : 1;               // C/D: lane (column v = l16, kq) holds beams kq + 4 i
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -1672,37 +1678,32 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       if (step + 1 < steps) {
         RV_STAMP_W1(d, step, 12);
         const int l16 = lane & 15, kq = lane >> 4;
-        const int aslot = ((l16 >> 2) + 4 * (l16 & 3)) & 7;
         const uint4* wimg = reinterpret_cast<const uint4*>(d.Wc16) + (size_t)wv * (32 * 128) + lane;   // pair p, part q: [(2 p + q) * 64]
-        const _Float16* xa = xim + (kq * 8 + aslot) * 8;     // k-step ks: + 256 ks; low part: + 2048
+        const _Float16* xa = xim + (kq * 16 + l16) * 8;      // k-step ks: + 512 ks (both parts of a beam in rows mx_row, + 1)
         constexpr int NS = 32 - NC - NR, NB = 4;             // streamed pairs
         f4v acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
         auto mm = [&](int p, const uint4& vh, const uint4& vl) {
           const int ks = p >> 2, g = p & 3;
-          const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
-          const h8 wh = __builtin_bit_cast(h8, vh), wl = __builtin_bit_cast(h8, vl);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[g], 0, 0, 0);
+          const h8 a = *reinterpret_cast<const h8*>(xa + ks * 512);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vl), acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vh), acc[g], 0, 0, 0);
         };
         if (wv == 0) {                                       // after the beam step: everything from LDS, one k-step (four gates) at a
           const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;   // time with the four accumulators taking turns (the waves that
 #pragma unroll                                                               // stream do not care: 87 cycles per MFMA at the link's rate)
           for (int ks = 0; ks < 8; ++ks) {
-            const h8 ah = *reinterpret_cast<const h8*>(xa + ks * 256), al = *reinterpret_cast<const h8*>(xa + 2048 + ks * 256);
+            const h8 a = *reinterpret_cast<const h8*>(xa + ks * 512);
             h8 wh[4], wl[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               wh[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g)) * 64]); wl[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g) + 1) * 64]);
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g], acc[g], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl[g], acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g], acc[g], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wh[g], acc[g], 0, 0, 0);
           }
         } else {
           uint4 bh[NB], bl[NB];
@@ -1726,13 +1727,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
             for (int r = 0; r < NR; ++r) mm(NS + r, rbh[r], rbl[r]);
           }
         }
-        // C/D: lane (column l16, kq) holds rows 4 kq + i = beams kq + 4 i
+        // C/D: lane (column l16, kq) holds rows 4 kq + i: registers 0 + 1 = beam kq (high- and low-part rows), 2 + 3 = beam kq + 4
         constexpr int NI = W > 4 ? 2 : 1;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int i = 0; i < NI; ++i)
-            if (kq + 4 * i < W) part[(kq + 4 * i) * ZS + RV_U * g + 16 * wv + l16] = acc[g][i] * d.mx_cdescale;
+            if (kq + 4 * i < W) part[(kq + 4 * i) * ZS + RV_U * g + 16 * wv + l16] = (acc[g][2 * i] + acc[g][2 * i + 1]) * d.mx_cdescale;
         RV_STAMP_W1(d, step, 13);
       }
     } else
