@@ -1690,20 +1690,30 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vl), acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vh), acc[g], 0, 0, 0);
         };
-        if (wv == 0) {                                       // after the beam step: everything from LDS, one k-step (four gates) at a
-          const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;   // time with the four accumulators taking turns (the waves that
-#pragma unroll                                                               // stream do not care: 87 cycles per MFMA at the link's rate)
-          for (int ks = 0; ks < 8; ++ks) {
-            const h8 a = *reinterpret_cast<const h8*>(xa + ks * 512);
-            h8 wh[4], wl[4];
+        // Wave 0 takes the output layer and the beam step first (4.7 k cycles); its columns' 32 pairs all sit in LDS (64 KB) and it takes
+        // them afterwards, half a k-step (two gates) at a time with the next half's fragments requested before this half's MFMAs.  (As a
+        // chain of whole k-steps, each waiting for its eight LDS reads -- round 3 -- the 32 pairs took 4.3 k cycles and the step ended
+        // 1.5 k cycles after the streaming waves had finished: C3 launch 0.342 -> 0.325 ms, R 0.916 -> 0.842 on one box, round-robin.
+        // Handing wave 0's columns to waves 1-4, one gate each between their own streamed pairs, measured SLOWER than either, 0.35 / 0.88:
+        // the extra LDS round trips delay the streaming waves' next requests, and with T_m > 256 there is no register for a prefetch.)
+        if (wv == 0) {
+          const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;       // pair p = 4 ks + g, part q: [(2 p + q) * 64]
+          uint4 fr[2][4];                                    // [buffer][(g0 high, g0 low, g1 high, g1 low)]
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              wh[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g)) * 64]); wl[g] = __builtin_bit_cast(h8, wc[(2 * (4 * ks + g) + 1) * 64]);
+          for (int j = 0; j < 4; ++j) fr[0][j] = wc[j * 64];
+#pragma unroll
+          for (int hs = 0; hs < 16; ++hs) {                  // half k-steps: k-step hs / 2, gates 2 (hs % 2), + 1
+            if (hs + 1 < 16) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) fr[(hs + 1) & 1][j] = wc[(4 * (hs + 1) + j) * 64];
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl[g], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wh[g], acc[g], 0, 0, 0);
+            const h8 a = *reinterpret_cast<const h8*>(xa + (hs >> 1) * 512);
+            const int g0 = 2 * (hs & 1);
+            acc[g0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, fr[hs & 1][1]), acc[g0], 0, 0, 0);
+            acc[g0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, fr[hs & 1][3]), acc[g0 + 1], 0, 0, 0);
+            acc[g0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, fr[hs & 1][0]), acc[g0], 0, 0, 0);
+            acc[g0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, fr[hs & 1][2]), acc[g0 + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         } else {
           uint4 bh[NB], bl[NB];
