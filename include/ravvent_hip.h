@@ -193,7 +193,9 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       0 = packed fp32 FMAs on fp32 rows.  Results agree to f32 rounding),
  *          "matrix_cell" (0/1, default 1; needs "matrix_attention": the same decode also takes the decoder cell's product
  *                       [attention | h] . [W_a ; U + A_h W_a] on the matrix pipe -- the kernel streamed as f16 MFMA fragments, two
- *                       parts per value, three exact part products per block; 0 = packed fp32 FMAs.  Results agree to f32 rounding),
+ *                       parts per value, three exact part products per block; 0 = packed fp32 FMAs.  Results agree to f32 rounding.
+ *                       With Bahdanau attention (one decoder cell) the same option moves the context, the processed query h . W_q, the
+ *                       cell product and the output layer to the matrix pipe; the tanh scores stay on the vector ALU),
  *          "persist_taps" (0/1, default 0: the persistent decode also records every step's logits [S,B,W,V] for
  *                       rv_get_tensor("step_logits"); rows of a chunk beyond its own last step ("chunk_steps") are not written),
  *          "profile"    (0 off; 1: hipEvents around every launch outside the decode graph and around

@@ -154,6 +154,10 @@ struct DecState {
   // [8 k-steps][2 parts][64 lanes][8 f16] (16 KB), rows divided like Wc16's, one power-of-two scale; mx_ldescale = its inverse.
   // Wave 0 takes the logits of all beams as 24 MFMAs on the [ctx' | h] image while the other waves already stream the cell product
   const uint16_t* Wl16; float mx_ldescale;
+  // Bahdanau on the matrix pipe (mx_attention == 2 with attention == 1): W_q [128][128] as B fragments of two f16 parts,
+  // [8 waves][4 k-steps][2 parts][64 lanes][8 f16] (64 KB): wave w owns columns 16 w .. 16 w + 15, lane (n, kq) of k-step ks holds
+  // T . W_q[32 ks + 8 kq + 0..7][16 w + n]; the A operand is the h half of the [ctx' | h] image (h 2^14): mx_qdescale = 2^-14 / T
+  const uint16_t* Wq16; float mx_qdescale;
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

@@ -905,9 +905,10 @@ constexpr int MXC_ZS = RV_G + 16;
 __host__ __device__ constexpr int part_floats_mxc(int W) { return W * MXC_ZS > PERSIST_MAX_NIT * 256 ? W * MXC_ZS : PERSIST_MAX_NIT * 256; }
 struct PersistLds {
   int attT, zb, cS, qp, part, ctxp, hcT, att, ml, mg, lg, fold, h0T, cS1, b1s, pq, vat, xim, wl16, wcache, total;
-  // ATT: 0 Luong on fp32 rows, 1 Bahdanau, 2 Luong on the matrix pipe, 3 = 2 + the cell product on the matrix pipe
+  // ATT: 0 Luong on fp32 rows, 1 Bahdanau, 2 Luong on the matrix pipe, 3 = 2 + the cell product on the matrix pipe,
+  // 4 = Bahdanau scores on the VALU (fp32 key rows) with context, cell product and output layer on the matrix pipe as in 3
   __host__ __device__ PersistLds(int W, int D = 1, int ATT = 0) {
-    const bool mxc = ATT == 3;
+    const bool mxc = ATT == 3 || ATT == 4;
     int o = 0;
     attT = o; if (!mxc) o += RV_U * WB;   // attention vectors k-major beam-minor (cell input rows 0..127); mxc: the f16 image `xim` instead
     zb = o; o += RV_MAX_VOCAB * RV_G;  // one-hot token rows of the cell kernel + bias: [V][512]
@@ -931,7 +932,7 @@ struct PersistLds {
       b1s = o; o += RV_G;
     }
     pq = o; vat = o;
-    if (ATT == 1) {                    // Bahdanau (basecaller.py:131-132): processed query (h . W_q) per beam, and attention_v
+    if (ATT == 1 || ATT == 4) {        // Bahdanau (basecaller.py:131-132): processed query (h . W_q) per beam, and attention_v
       pq = o; o += W * RV_U;
       vat = o; o += RV_U;
     }
@@ -952,14 +953,15 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
                                                       const float* __restrict__ Wcat1 /*D == 2: [256,512] = [W_1 ; U_1]*/, const float* __restrict__ bdec1,
                                                       const float* __restrict__ Nh /*D == 1: A_h . W_fc [128,V]*/) {
   constexpr int NT = 512;
-  constexpr bool BAH = ATT == 1;           // Bahdanau scores on the VALU
-  constexpr bool MX = ATT >= 2;            // Luong attention (scores and context) on the matrix pipe, split-f16 operands
-  constexpr bool MXC = ATT == 3;           // ... and the cell product [ctx' | h] . Wcat2 (weights as B fragments from the Wc16 image)
+  constexpr bool BAH = ATT == 1 || ATT == 4;   // Bahdanau scores on the VALU (fp32 key rows)
+  constexpr bool MX = ATT >= 2;            // the context on the matrix pipe (U' resident as f16 B fragments, alignments through an LDS image)
+  constexpr bool MXS = ATT == 2 || ATT == 3;   // ... and the Luong scores (keys resident as f16 B fragments, query through an LDS image)
+  constexpr bool MXC = ATT == 3 || ATT == 4;   // ... and the cell product [ctx' | h] . Wcat2 and the output layer (weights as B fragments: Wc16, Wl16)
   constexpr int ZS = MXC ? MXC_ZS : RV_G;  // row stride of the gate pre-activations in `part`
   constexpr int NC = mxc_nc(W);
-  constexpr int NR = (MXC && NIT <= 8) ? 5 : 0;   // T_m <= 256 leaves ~50 registers: waves 1-7 keep NR more (k-step, gate) pairs of their share there
+  constexpr int NR = (ATT == 3 && NIT <= 8) ? 5 : 0;   // T_m <= 256 leaves ~50 registers: waves 1-7 keep NR more (k-step, gate) pairs of their share there
   static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
-  static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= (ATT == 3 ? part_floats_mxc(W) : part_floats(W)), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
+  static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= (MXC ? part_floats_mxc(W) : part_floats(W)), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
   static_assert(2 * 1024 * sizeof(_Float16) /* query image: 2 parts x [16 k-blocks][8 slots][8] f16 */ <= (8 * 4 * 2 * 16 * 4) * sizeof(float), "the query image must fit `fold`");
   extern __shared__ __align__(16) float dsm[];
   const PersistLds L(W, D, ATT);
@@ -974,9 +976,9 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   // output layer weights, transposed to [v][k] (rows padded to 132 floats: the 8-lane groups of two outputs then read different banks)
   constexpr int FCW = RV_U + 4;
   // (the matrix-pipe form takes the output layer from the Wl16 fragments: it only needs the bias here, and neither `qp` nor `att`)
-  __shared__ __align__(16) float s_wfc[(ATT == 3 ? 0 : RV_MAX_VOCAB * FCW) + RV_MAX_VOCAB];
-  __shared__ __align__(16) float s_nh[(D == 1 && ATT != 3) ? RV_MAX_VOCAB * FCW : 4];
-  constexpr int BFC = ATT == 3 ? 0 : RV_MAX_VOCAB * FCW;      // offset of b_fc in s_wfc
+  __shared__ __align__(16) float s_wfc[(MXC ? 0 : RV_MAX_VOCAB * FCW) + RV_MAX_VOCAB];
+  __shared__ __align__(16) float s_nh[(D == 1 && !MXC) ? RV_MAX_VOCAB * FCW : 4];
+  constexpr int BFC = MXC ? 0 : RV_MAX_VOCAB * FCW;      // offset of b_fc in s_wfc
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
 
@@ -990,16 +992,16 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   //      pass over the registers scores two rows.  U' (the context side): every lane 8 columns of each of the stream's rows.
   constexpr int NP = (NIT + 1) / 2;
   const int half = sub >> 3, s8 = sub & 7;
-  float4 kr[MX ? 1 : NP][4], ur[MX ? 1 : NIT][2];
+  float4 kr[MXS ? 1 : NP][4], ur[MX ? 1 : NIT][2];
   // MX: the same memory as MFMA B fragments (v_mfma_f32_16x16x32_f16), two f16 parts of the scaled values each.  Scores: wave
   // wv owns the 16-step tiles wv + 8 c; lane (n = step l % 16 of the tile, kq = l / 16) holds key[t][32 ks + 8 kq + 0..7].
   // Context: wave wv owns units 16 wv .. 16 wv + 15; lane (n = unit, kq) holds U'[32 ks + 8 kq + 0..7][unit].  The scales are
   // powers of two from the weights (|key| <= sum_k |W_mem[k][u]| because |enc_out| <= 1): nothing can overflow f16, and what
   // falls into its subnormals is below 2^-28 of the largest value the column can take.
   constexpr int NTT = (2 * NIT + 7) / 8;
-  float4 kb[MX ? NTT : 1][4][2], ub[MX ? NIT : 1][2];
+  float4 kb[MXS ? NTT : 1][4][2], ub[MX ? NIT : 1][2];
   unsigned livebits = 0;
-  if constexpr (MX) {
+  if constexpr (MXS) {
     const float* cbase = d.values + (size_t)b * Tm * RV_E;
     const uint8_t* mrow = d.mask + (size_t)b * Tm;
     const int l16 = lane & 15, kq = lane >> 4, wv0 = tid >> 6;
@@ -1015,6 +1017,10 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       if (t < Tm && mrow[tc]) livebits |= 1u << c;          // _maybe_mask_score: padded steps never score
     }
+  }
+  if constexpr (MX) {
+    const float* cbase = d.values + (size_t)b * Tm * RV_E;
+    const int l16 = lane & 15, kq = lane >> 4, wv0 = tid >> 6;
 #pragma unroll
     for (int ks = 0; ks < NIT; ++ks) {
       float v[8];
@@ -1022,7 +1028,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       for (int j = 0; j < 8; ++j) v[j] = cbase[(size_t)min(32 * ks + 8 * kq + j, Tm - 1) * RV_E + RV_U + 16 * wv0 + l16];
       split_f16x8(v, d.mx_uscale, ub[ks][0], ub[ks][1]);
     }
-  } else {
+  }
+  if constexpr (!MXS) {
     const float* cbase = d.values + (size_t)b * Tm * RV_E;
     const uint8_t* mrow = d.mask + (size_t)b * Tm;
 #pragma unroll
@@ -1040,9 +1047,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int t = sid + 32 * it, tc = min(t, Tm - 1);
-      const float* q = cbase + (size_t)tc * RV_E + RV_U + 4 * sub;
+      if constexpr (!MX) {
+        const float* q = cbase + (size_t)tc * RV_E + RV_U + 4 * sub;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) ur[it][m] = *reinterpret_cast<const float4*>(q + 64 * m);
+        for (int m = 0; m < 2; ++m) ur[it][m] = *reinterpret_cast<const float4*>(q + 64 * m);
+      }
       if (t < Tm && mrow[tc]) livebits |= 1u << it;       // _maybe_mask_score: padded steps never score
     }
   }
@@ -1129,7 +1138,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
 #pragma unroll
       for (int u = 0; u < 8; ++u) pw[u] = *reinterpret_cast<const float4*>(wq + (size_t)u * RV_U);
     };
-    if (BAH) wq_prefetch();
+    // Bahdanau + matrix pipe: this wave's B fragments of W_q (its 16 columns, K = 128: 4 k-steps x 2 parts), requested before the gate math
+    uint4 wqf[(BAH && MXC) ? 8 : 1];
+    if constexpr (BAH && MXC) {
+      const uint4* wq = reinterpret_cast<const uint4*>(d.Wq16) + (size_t)wv * (8 * 64) + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wqf[j] = wq[j * 64];
+    } else if (BAH) wq_prefetch();
     if constexpr (MXC) {
       // W * 128 (beam, unit) items on 512 threads: waves 0-1 take two (W = 5).  Both items' operands are read first, then both are
       // computed, then stored: the second item rides in the first one's LDS and transcendental latencies instead of doubling the phase.
@@ -1158,7 +1173,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
           _Float16* xq = xim + (((RV_U + u) >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
           xq[0] = hi; xq[8] = lo;
         }
-        {   // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
+        if constexpr (MXS) {   // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
           const float sv = (hh * LOG2E) * 16384.f;
           const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
           _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
@@ -1179,7 +1194,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       const float hh = rv_sigmoid(z4[3]) * rv_tanh(c2);
       cS[(cb ^ 1) * W * RV_U + idx] = c2;
       if (D > 1) h0T[u * WB + w] = hh; else { hcT[u * WB + w] = hh; qp[idx] = hh * LOG2E; }
-      if constexpr (MX) {      // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
+      if constexpr (MXS) {     // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
         const float sv = (hh * LOG2E) * 16384.f;
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
         _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
@@ -1237,7 +1252,23 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       __syncthreads();
     }
-    if (BAH) {
+    if constexpr (BAH && MXC) {
+      // ================= Bahdanau: processed query pq = h . W_q (BahdanauAttention.query_layer, no bias) on the matrix pipe: A = the h rows
+      //   of the [ctx' | h] image (k-steps 4..7), B = this wave's 16 columns of W_q (Wq16, requested before the gate math): complete in the wave
+      const int l16 = lane & 15, kq = lane >> 4;
+      const _Float16* xa = xim + (kq * 16 + l16) * 8;
+      f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h8 a = *reinterpret_cast<const h8*>(xa + (4 + ks) * 512);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, wqf[2 * ks]), a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, wqf[2 * ks + 1]), a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < (W > 4 ? 2 : 1); ++i)
+        if (kq + 4 * i < W) pqs[(kq + 4 * i) * RV_U + 16 * wv + l16] = ((a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1])) * (d.mx_qdescale * 2.0f * LOG2E);
+      __syncthreads();
+    } else if (BAH) {
       // ================= Bahdanau: processed query pq = h . W_q (BahdanauAttention.query_layer, no bias); thread = (4 columns,
       //   1 of 16 K groups of 8 rows), partial sums through `part` (free between the gates and the context phase)
       const int d4 = tid & 31, kg = tid >> 5;
@@ -1294,7 +1325,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     RV_STAMP(d, step, 3);
 
-    if constexpr (MX) {
+    if constexpr (MXS) {
       // ================= scores on the matrix pipe: rows = beams, columns = the 16 steps of a tile, K = 128 units.
       //   C/D map: lane l holds column l % 16 and rows 4 g + i (g = l / 16).  Beam w sits in rows mx_row(w), + 1 (its high and its low
       //   part: see mx_row), so that registers 0 + 1 hold beams 0-3 (one per 16-lane group, all 64 lanes busy) and 2 + 3 beams 4-7: the
@@ -1382,36 +1413,6 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
       __syncthreads();
       RV_STAMP(d, step, 5);
-      // ================= attention-layer context part = sum_t alpha_t U'_t on the matrix pipe: rows = beams, this wave's 16 units,
-      //   K = the chunk's steps; the product is complete in one wave (no partial sums to merge)
-      {
-        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 16 + l16) * 8;
-        f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;           // against the high / the low part of U'
-#pragma unroll
-        for (int ks = 0; ks < NIT; ++ks) {
-          const h8 a = *reinterpret_cast<const h8*>(aa + ks * 512);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][0]), a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][1]), a1, 0, 0, 0);
-        }
-        float acc[2];                                      // beams kq, kq + 4
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = (a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1]);
-        RV_STAMP(d, step, 6);
-        const int col = 16 * wv + l16;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-          if (kq + 4 * i < W) {
-            const float av = acc[i] * d.mx_udescale;
-            if constexpr (!MXC) att[(kq + 4 * i) * RV_U + col] = av;
-            if constexpr (MXC) {   // ctx' as A fragments of the cell product: k = col, ctx' . mx_uscale (= acc 2^-14, below 2^14) in two f16 parts
-              const float sv = acc[i] * (1.0f / 16384.f);
-              const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-              _Float16* xq = xim + ((col >> 3) * 16 + mx_row(kq + 4 * i)) * 8 + (col & 7);
-              xq[0] = hi; xq[8] = lo;
-            } else attT[col * WB + kq + 4 * i] = av;
-          }
-      }
-      __syncthreads();
     } else {
     // ================= scores from the resident key rows: lane w keeps beam w's score of the even row of a pair, lane 8 + w
     //   that of the odd row
@@ -1482,6 +1483,25 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       for (int p = 0; p < NP; ++p) sc[p] = m == -INFINITY ? nanv : sc[p] * f;   // alignments of beam s8 on this half's rows
     }
     RV_STAMP(d, step, 5);
+    if constexpr (MX) {
+      // ================= (Bahdanau on the matrix pipe) the alignments this lane holds -- beam s8 on rows t = sid + 32 (2 p + half) -- as the
+      //   context product's A fragments: [k-block t / 8][row mx_row(beam) (+ 1: low part)][t % 8] f16 of alpha 2^14, in `part` (idle
+      //   between the gates and the cell product at the end of the step); padded steps carry an alignment of exactly 0
+      if (s8 < W) {
+        _Float16* aa = reinterpret_cast<_Float16*>(part);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int it = 2 * p + half, t = sid + 32 * it;
+          if (it < NIT) {
+            const float av = sc[p] * 16384.f;
+            const _Float16 hi = (_Float16)av, lo = (_Float16)(av - (float)hi);
+            _Float16* q = aa + ((t >> 3) * 16 + mx_row(s8)) * 8 + (t & 7);
+            q[0] = hi; q[8] = lo;
+          }
+        }
+      }
+      __syncthreads();
+    } else {
     // ================= attention-layer context part = sum_t alpha_t * U'_t, one beam at a time (8-register accumulator)
     {
       float4* slab = reinterpret_cast<float4*>(fold + (size_t)wv * (4 * 2 * 16 * 4));
@@ -1530,6 +1550,42 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       att[i] = av; attT[col * WB + w] = av;
     }
     __syncthreads();
+    
+    }
+    }
+    if constexpr (MX) {
+      const int l16 = lane & 15, kq = lane >> 4;
+      constexpr int NI = W > 4 ? 2 : 1;
+      // ================= attention-layer context part = sum_t alpha_t U'_t on the matrix pipe: rows = beams, this wave's 16 units,
+      //   K = the chunk's steps; the product is complete in one wave (no partial sums to merge)
+      {
+        const _Float16* aa = reinterpret_cast<const _Float16*>(part) + (kq * 16 + l16) * 8;
+        f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;           // against the high / the low part of U'
+#pragma unroll
+        for (int ks = 0; ks < NIT; ++ks) {
+          const h8 a = *reinterpret_cast<const h8*>(aa + ks * 512);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][0]), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, ub[ks][1]), a1, 0, 0, 0);
+        }
+        float acc[2];                                      // beams kq, kq + 4
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = (a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1]);
+        RV_STAMP(d, step, 6);
+        const int col = 16 * wv + l16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (kq + 4 * i < W) {
+            const float av = acc[i] * d.mx_udescale;
+            if constexpr (!MXC) att[(kq + 4 * i) * RV_U + col] = av;
+            if constexpr (MXC) {   // ctx' as A fragments of the cell product: k = col, ctx' . mx_uscale (= acc 2^-14, below 2^14) in two f16 parts
+              const float sv = acc[i] * (1.0f / 16384.f);
+              const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+              _Float16* xq = xim + ((col >> 3) * 16 + mx_row(kq + 4 * i)) * 8 + (col & 7);
+              xq[0] = hi; xq[8] = lo;
+            } else attT[col * WB + kq + 4 * i] = av;
+          }
+      }
+      __syncthreads();
     }
     RV_STAMP(d, step, 8);
     // ================= logits = attention . W_fc + b_fc
@@ -1934,14 +1990,15 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
   if constexpr (W <= 5) {
     if (d.depth > 1) { launch_persist_wd<W, 2, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
-  if (d.attention == 1) launch_persist_wd<W, 1, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);     // Bahdanau: one decoder cell
+  if (d.attention == 1 && d.mx_attention == 2) launch_persist_wd<W, 1, 4>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);   // Bahdanau: scores on the VALU, the rest on the matrix pipe
+  else if (d.attention == 1) launch_persist_wd<W, 1, 1>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);     // Bahdanau: one decoder cell, packed FMAs
   else if (d.mx_attention == 2) launch_persist_wd<W, 1, 3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);  // Luong, attention and cell product on the matrix pipe
   else if (d.mx_attention) launch_persist_wd<W, 1, 2>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);  // Luong, scores and context on the matrix pipe
   else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  const int att_form = d.attention == 1 ? 1 : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0);
-  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, att_form).total + (att_form == 3 ? MXC_STATIC_LDS : 10 * 1024) > 160 * 1024) return false;   // dynamic + static LDS
+  const int att_form = d.attention == 1 ? (d.depth == 1 && d.mx_attention == 2 ? 4 : 1) : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0);
+  if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, att_form).total + (att_form >= 3 ? MXC_STATIC_LDS : 10 * 1024) > 160 * 1024) return false;   // dynamic + static LDS
   return (d.attention == 0 || (d.attention == 1 && d.depth == 1)) && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
 void launch_dec_persist(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
@@ -2044,6 +2101,9 @@ static hipError_t configure_w() {
   opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
   opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
   opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 3>), sizeof(float) * PersistLds(W, 1, 3).total);
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 1, 4>), sizeof(float) * PersistLds(W, 1, 4).total);
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 4>), sizeof(float) * PersistLds(W, 1, 4).total);
+  opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 4>), sizeof(float) * PersistLds(W, 1, 4).total);
   if constexpr (W <= 5) {
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);

@@ -77,6 +77,8 @@ struct RvContext {
   float mx_cdescale = 1.f;                  // 1 / the power-of-two scale of the Wc16 image (set by rv_load_weights)
   float mx_ldescale = 1.f;                  // ... of the Wl16 image
   uint16_t* d_Wl16 = nullptr;               // derived (one decoder cell): [W_fc ; A_h W_fc] as MFMA B fragments (DecState::Wl16)
+  uint16_t* d_Wq16 = nullptr;               // derived (Bahdanau, one decoder cell): W_q as MFMA B fragments (DecState::Wq16)
+  float mx_qdescale = 1.f;
   float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
   uint16_t* d_Ua = nullptr;                 // derived: recurrent kernels as MFMA A fragments (two f16 parts) + row factors, [enc][layer][dir][RV_UA_SLOT]
   uint16_t* d_Wx16 = nullptr;               // derived: input kernels of encoder layers >= 1, both directions, as the split GEMM's B slabs, [enc][layer-1][RV_WX16_SLOT]
@@ -611,8 +613,11 @@ int record_slab(RvContext* h, const float* xr, const float* xe, bool host_in, in
   // keep sampling after their end token, so greedy decodes as one piece).
   int nsplit = (greedy || h->opt_taps || B < 64) ? 1 : std::min(std::max(h->opt_split, 1), 4);
   d.chunk_steps = nullptr;
-  d.mx_attention = (h->opt_mx_att && c.attention == RV_ATT_LUONG && d.depth == 1) ? (h->opt_mx_cell ? 2 : 1) : 0;   // (sizes the decode's LDS)
+  // (sizes the decode's LDS)  Luong: 1 = scores and context on the matrix pipe, 2 = the cell product and the output layer too; Bahdanau: 2 = the
+  // context, the processed query, the cell product and the output layer on the matrix pipe (the tanh scores stay on the VALU), else packed FMAs
+  d.mx_attention = (h->opt_mx_att && d.depth == 1) ? (h->opt_mx_cell ? 2 : (c.attention == RV_ATT_LUONG ? 1 : 0)) : 0;
   d.Wc16 = h->d_Wc16; d.mx_cdescale = h->mx_cdescale; d.Wl16 = h->d_Wl16; d.mx_ldescale = h->mx_ldescale;
+  d.Wq16 = h->d_Wq16; d.mx_qdescale = h->mx_qdescale;
   h->lpersist = (persist_ok && dec_persist_supported(d)) ? 1 : 0;
   if (persist_ok && !h->lpersist) return fail(h, RV_ESTATE, "internal: persistent decode predicate mismatch");
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
@@ -867,6 +872,7 @@ int create_child(RvContext* p, RvContext** out) {
   h->d_w = p->d_w; h->n_w = p->n_w;
   h->d_WmemT = p->d_WmemT; h->d_Up = p->d_Up; h->d_Wp = p->d_Wp; h->d_Wsb = p->d_Wsb; h->d_Wh = p->d_Wh; h->d_Ua = p->d_Ua;
   h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16; h->d_Wc16 = p->d_Wc16; h->d_Wl16 = p->d_Wl16;
+  h->d_Wq16 = p->d_Wq16;
   h->d_WcatT = p->d_WcatT;
   bind_weights(h);
   const int rc = alloc_slab_buffers(h);
@@ -880,6 +886,7 @@ void sync_child(RvContext* k, const RvContext* p) {
   k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
   k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
   k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->mx_ldescale = p->mx_ldescale; k->opt_tail_wave = p->opt_tail_wave;
+  k->mx_qdescale = p->mx_qdescale;
   k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
   k->opt_taps = 0; k->opt_ptaps = 0;      // debug taps belong to the synchronous calls
   k->inflight_hint = p->inflight_hint;
@@ -947,6 +954,7 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_Wmp16, RV_WMP16_SLOT));
   TRY(dalloc(h, &h->d_Wc16, (size_t)2 * RV_E * RV_G));
   TRY(dalloc(h, &h->d_Wl16, (size_t)2 * RV_E * 16));
+  TRY(dalloc(h, &h->d_Wq16, (size_t)2 * RV_U * RV_U));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
   TRY(dalloc(h, &h->d_Nh, (size_t)RV_U * RV_MAX_VOCAB));
   TRY(dalloc(h, &h->d_Up, (size_t)2 * c.enc_depth * 2 * RV_U * RV_G));
@@ -1256,6 +1264,28 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
               li[(((size_t)ks * 2 + 1) * 64 + ln) * 8 + j] = lb;
             }
         HIPCHK(h, hipMemcpy(h->d_Wl16, li.data(), li.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        {   // Bahdanau's query layer W_q [128][128] for the matrix pipe (DecState::Wq16): one power-of-two scale, two f16 parts, per-wave B fragments
+          const size_t qo = (size_t)(h->W_q - h->d_w);
+          float mq = 0.f;
+          for (size_t i = 0; i < (size_t)RV_U * RV_U; ++i) mq = std::max(mq, std::fabs(blob[qo + i]));
+          int eq = 0;
+          if (mq > 0.f && std::isfinite(mq)) std::frexp(mq, &eq);
+          const float Tq = std::ldexp(1.0f, 14 - eq);
+          h->mx_qdescale = std::ldexp(1.0f, -14) / Tq;
+          std::vector<uint16_t> qi((size_t)2 * RV_U * RV_U);
+          for (int wv = 0; wv < 8; ++wv)
+            for (int ks = 0; ks < 4; ++ks)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                  const float v = blob[qo + (size_t)(32 * ks + 8 * (ln >> 4) + j) * RV_U + 16 * wv + (ln & 15)] * Tq;
+                  const _Float16 hi = (_Float16)v;
+                  const _Float16 lo = (_Float16)(v - (float)hi);
+                  uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                  qi[((((size_t)wv * 4 + ks) * 2 + 0) * 64 + ln) * 8 + j] = hb;
+                  qi[((((size_t)wv * 4 + ks) * 2 + 1) * 64 + ln) * 8 + j] = lb;
+                }
+          HIPCHK(h, hipMemcpy(h->d_Wq16, qi.data(), qi.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
       }
     }
     const size_t moff = (size_t)(h->W_mem - h->d_w);       // W_mem [256][128] -> [128][256]

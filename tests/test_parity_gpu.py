@@ -927,43 +927,59 @@ def test_sharded_two_ranks_on_one_gpu(rv):
     bc.close()
 
 
-@pytest.mark.parametrize("B,Tr,Te,W,L", [(9, 120, 20, 5, 20), (6, 300, 30, 5, 24), (5, 40, 8, 1, 12), (4, 60, 0, 8, 14), (3, 307, 45, 3, 10)])
+@pytest.mark.parametrize("B,Tr,Te,W,L", [(9, 120, 20, 5, 20), (6, 300, 30, 5, 24), (5, 40, 8, 1, 12), (4, 60, 0, 8, 14), (3, 307, 45, 3, 10), (7, 200, 30, 6, 16)])
 def test_bahdanau_persistent_decode(rv, oracle, B, Tr, Te, W, L):
     """Bahdanau attention (Decoder(attention_type='bahdanau'), basecaller.py:131-132; north_star) on the one-launch persistent
-    decode: == the per-step kernels (exact reference dataflow: scores from keys, tanh, context from values) == the fp64
-    oracle; per-step logits of the persistent kernel within 1e-4; greedy logits within 1e-4."""
+    decode, in its two forms -- the default since round 4: tanh scores on the vector ALU, processed query h . W_q, context, cell product
+    and output layer on the matrix pipe (split-f16 operands: option matrix_cell = 1); and everything on packed fp32 FMAs (matrix_cell =
+    0) -- == the per-step kernels (exact reference dataflow: scores from keys, tanh, context from values) == the fp64 oracle; per-step
+    logits of both persistent forms within 1e-4 of fp64 and within 2e-5 of each other, ids / parents identical; greedy logits within
+    1e-4.  Weights scaled up (gain 1.5: larger keys and queries) and a chunk with most of its raw steps padded."""
     mode = "joint" if Te else "raw"
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, attention_type="bahdanau", honor_attention_type=True,
                        max_batch=16, max_raw_len=320)
-    flat = rv.weights.init_weights(bc.cfg, seed=19)
+    flat = rv.weights.init_weights(bc.cfg, seed=19, gain=1.5)
     flat["b_fc"][bc.cfg.end_token] = 0.5
+    flat["W_q"][:, 7] *= 6.0; flat["W_q"][3, :] *= 1e-3          # an outlier column and a tiny row in the query layer's split image
     bc.set_weights_flat(flat)
     w = rv.weights.flat_to_nested(bc.cfg, flat)
     raw, ev, _ = rv.synthetic.make_slab(B, Tr, max(Te, 1), seed=B + W)
     raw[1, Tr // 2:] = 0.0
     x = (raw, ev) if mode == "joint" else raw
-    out = {}
+    out, lg, ids, par, cs = {}, {}, {}, {}, {}
     bc.set_option("profile", 1)
     bc.set_option("persist_taps", 1)
-    for persist in (1, 0):
+    for form, (persist, mcell) in {"mx": (1, 1), "fma": (1, 0), "steps": (0, 1)}.items():
         bc.set_option("persistent_decode", persist)
+        bc.set_option("matrix_cell", mcell)
         bc.reset_profile()
         tok, sc = bc.beam_search_prediction(x, W, L)
         assert ("dec_persist" in bc.profile()) == bool(persist)
-        out[persist] = (tok.numpy().copy(), sc.numpy().copy())
+        out[form] = (tok.numpy().copy(), sc.numpy().copy())
         if persist:
-            lg = bc.get_tensor("step_logits").reshape(tok.shape[1], B, W, 7)
-            cs = bc.get_tensor("chunk_steps").astype(int)
-    assert out[1][0].shape == out[0][0].shape and (out[1][0] == out[0][0]).all() and np.abs(out[1][1] - out[0][1]).max() < TOL
+            S = tok.shape[1]
+            lg[form] = bc.get_tensor("step_logits").reshape(S, B, W, 7).copy()
+            ids[form] = bc.get_tensor("step_ids").reshape(S, B, W).copy()
+            par[form] = bc.get_tensor("parent_ids").reshape(S, B, W).copy()
+            cs[form] = bc.get_tensor("chunk_steps").astype(int)
     taps = {}
     ot, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, W, L, dtype=np.float64, taps=taps)
-    assert out[1][0].shape == ot.shape and (out[1][0] == ot).all() and np.abs(out[1][1] - osc).max() < TOL
+    for form in ("mx", "fma", "steps"):
+        assert out[form][0].shape == ot.shape and (out[form][0] == ot).all() and np.abs(out[form][1] - osc).max() < TOL, form
+    assert (cs["mx"] == cs["fma"]).all()
+    for form in ("mx", "fma"):
+        for b in range(B):
+            n = cs[form][b]
+            assert np.abs(lg[form][:n, b] - taps["step_logits"][:n, b]).max() < TOL, (form, b)
+            assert (ids[form][:n, b] == taps["step_ids"][:n, b]).all() and (par[form][:n, b] == taps["parent_ids"][:n, b]).all(), (form, b)
     for b in range(B):
-        assert np.abs(lg[:cs[b], b] - taps["step_logits"][:cs[b], b]).max() < TOL, b
-    bc.set_option("persistent_decode", 1)
-    g, glg = bc.greedy_search_prediction(x, L)
-    og, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, L)
-    assert g.shape == og.shape and (g.numpy() == og).all() and np.abs(glg.numpy() - olg).max() < TOL
+        n = cs["mx"][b]
+        assert np.abs(lg["mx"][:n, b] - lg["fma"][:n, b]).max() < 2e-5, b
+    for mcell in (1, 0):
+        bc.set_option("persistent_decode", 1); bc.set_option("matrix_cell", mcell)
+        g, glg = bc.greedy_search_prediction(x, L)
+        og, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw, ev if mode == "joint" else None, L)
+        assert g.shape == og.shape and (g.numpy() == og).all() and np.abs(glg.numpy() - olg).max() < TOL, mcell
     bc.close()
 
 
