@@ -16,6 +16,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -981,6 +982,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr int BFC = MXC ? 0 : RV_MAX_VOCAB * FCW;      // offset of b_fc in s_wfc
   __shared__ float s_lprob[WB];
   __shared__ int s_fin[WB], s_len[WB], s_parent[WB], s_tok[WB], s_allfin;
+  __shared__ int s_qbig;                   // Bahdanau on the matrix pipe: some processed query of this step lies outside the fast form's range
 
   const int b = blockIdx.x, tid = threadIdx.x, Tm = d.Tm, V = d.V;
   const int lane = tid & 63, sub = lane & 15, sid = tid >> 4;
@@ -1055,6 +1057,31 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       if (t < Tm && mrow[tc]) livebits |= 1u << it;       // _maybe_mask_score: padded steps never score
     }
   }
+  // Bahdanau on the matrix pipe: tanh(k + q) = 1 - 2 / (1 + 2^(k' + q')) with k' = 2 log2(e) k, and 2^(k' + q') = 2^k' . 2^q': the resident
+  // rows hold E_k = 2^k' (ONE exponential per key element for the whole decode), a step's queries come as E_q = 2^q', and a score element
+  // costs a multiply-add and ONE reciprocal instead of an exponential and a reciprocal -- the loop is bound by the transcendental rate
+  // (16 lanes per clock and CU).  Exact for |k'| <= 64 and |q'| <= 60 (the product stays a normal f32: |k| <= 22, |h . W_q| <= 20);
+  // a chunk with a larger key keeps k' and takes the two-transcendental form for all its steps, a step with a larger query takes
+  // 2^(log2(E_k) + q') -- both block-uniform choices, neither ever seen with weights of any plausible scale.
+  bool kbig = false;
+  if constexpr (BAH && MXC) {
+    bool big = false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        big = big || !(fabsf(kr[p][m].x) <= 64.f && fabsf(kr[p][m].y) <= 64.f && fabsf(kr[p][m].z) <= 64.f && fabsf(kr[p][m].w) <= 64.f);
+    kbig = __syncthreads_or(big ? 1 : 0) != 0;
+    if (!kbig) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          kr[p][m].x = __builtin_amdgcn_exp2f(kr[p][m].x); kr[p][m].y = __builtin_amdgcn_exp2f(kr[p][m].y);
+          kr[p][m].z = __builtin_amdgcn_exp2f(kr[p][m].z); kr[p][m].w = __builtin_amdgcn_exp2f(kr[p][m].w);
+        }
+    }
+  }
   // ---- decoder initial state: zeros; start tokens; log_probs = [0, -inf, ...]
   // The cell's matrix-vector product of a step is taken on the PREVIOUS step's beams, before they are re-ordered (it only
   // needs their attention vector and h); the gate math then picks up the partial sums and the cell state of its parent
@@ -1119,6 +1146,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, sid = tid >> 4, row = lane >> 4;
     RV_STAMP(d, step, 0);
+    if (BAH && MXC && tid == 0) s_qbig = 0;              // (set again, if at all, after the gates' barrier; last read before this step's last barrier)
     // ================= gates of this step: the cell product was taken at the end of the previous step on the parent beams
     const int cb = step & 1;                             // cell-state buffer holding the previous step's states
     // The chunk's resident rows are [keys | U'] = values . [W_mem | A_c] (A_c = the attention layer's context rows), built once
@@ -1266,7 +1294,12 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
 #pragma unroll
       for (int i = 0; i < (W > 4 ? 2 : 1); ++i)
-        if (kq + 4 * i < W) pqs[(kq + 4 * i) * RV_U + 16 * wv + l16] = ((a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1])) * (d.mx_qdescale * 2.0f * LOG2E);
+        if (kq + 4 * i < W) {
+          const float qv = ((a0[2 * i] + a0[2 * i + 1]) + (a1[2 * i] + a1[2 * i + 1])) * (d.mx_qdescale * 2.0f * LOG2E);
+          pqs[(kq + 4 * i) * RV_U + 16 * wv + l16] = qv;                       // q' ...
+          fold[(kq + 4 * i) * RV_U + 16 * wv + l16] = __builtin_amdgcn_exp2f(fminf(fmaxf(qv, -126.f), 126.f));   // ... and E_q = 2^q' (`fold` holds no query image here)
+          if (!(fabsf(qv) <= 60.f)) s_qbig = 1;
+        }
       __syncthreads();
     } else if (BAH) {
       // ================= Bahdanau: processed query pq = h . W_q (BahdanauAttention.query_layer, no bias); thread = (4 columns,
@@ -1419,6 +1452,43 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     float sc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) sc[p] = -INFINITY;
+    if constexpr (BAH && MXC) {
+      // score_t log2(e) = const + sum_j v'_j / (1 + 2^(k'_tj + q'_j)) (see the resident rows above): MODE 1 = E_k . E_q + 1, one reciprocal;
+      // MODE 0 = the chunk kept k' (a key out of range); MODE 2 = this step has a query out of range
+      auto bah_scores = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const float* qsrc = MODE == 1 ? fold : pqs;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          float4 qv[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4*>(&qsrc[w * RV_U + 16 * s8 + 4 * m]);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            f2 pp = f2{0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const float4 vv = *reinterpret_cast<const float4*>(&vat[16 * s8 + 4 * m]);
+              auto el = [&](float k, float q) -> float {
+                if constexpr (MODE == 1) return __builtin_amdgcn_rcpf(fmaf(k, q, 1.0f));
+                else if constexpr (MODE == 0) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k + q));
+                else return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(k) + q));
+              };
+              const float r0 = el(kr[p][m].x, qv[m].x), r1 = el(kr[p][m].y, qv[m].y), r2 = el(kr[p][m].z, qv[m].z), r3 = el(kr[p][m].w, qv[m].w);
+              pp = __builtin_elementwise_fma(f2{vv.x, vv.y}, f2{r0, r1}, pp);
+              pp = __builtin_elementwise_fma(f2{vv.z, vv.w}, f2{r2, r3}, pp);
+            }
+            float sw = pp.x + pp.y;
+            sw += dpp<0xB1>(sw); sw += dpp<0x4E>(sw); sw += dpp<0x141>(sw);      // the 8 lanes of this half row
+            const int it = 2 * p + half;
+            sc[p] = (s8 == w && it < NIT && ((livebits >> it) & 1u)) ? sw : sc[p];
+          }
+        }
+      };
+      if (kbig) bah_scores(std::integral_constant<int, 0>{});
+      else if (s_qbig) bah_scores(std::integral_constant<int, 2>{});
+      else bah_scores(std::integral_constant<int, 1>{});
+    } else
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       float4 qv[4];

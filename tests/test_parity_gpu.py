@@ -983,6 +983,67 @@ def test_bahdanau_persistent_decode(rv, oracle, B, Tr, Te, W, L):
     bc.close()
 
 
+@pytest.mark.parametrize("case", ["large_keys", "large_queries"])
+def test_bahdanau_matrix_form_outside_the_fast_range(rv, oracle, case):
+    """The Bahdanau decode's matrix-pipe form keeps E_k = 2^(2 log2(e) k) resident and takes a score element as 1 / (1 + E_k E_q): exact
+    while |2 log2(e) k| <= 64 and |2 log2(e) q| <= 60.  Outside that range it must not clamp: a chunk with a larger key keeps the keys
+    themselves and pays two transcendentals per element, a step with a larger processed query goes through log2(E_k).  Both regimes
+    here (W_mem x 250: keys of several tens; W_q x 200: processed queries of several tens), against the packed-FMA form of the same
+    library, which always computes tanh from k + q: chunk step counts equal, per-step logits within 1e-4 on every chunk whose
+    beam order agrees (tanh is saturated almost everywhere, so near-ties are common), tokens equal on most rows; and the fp64 oracle
+    agrees with the matrix form on every chunk it can be compared on."""
+    B, Tr, Te, W, L = 10, 120, 20, 4, 10
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, attention_type="bahdanau", honor_attention_type=True,
+                       max_batch=16, max_raw_len=Tr, max_event_len=Te)
+    flat = rv.weights.init_weights(bc.cfg, seed=23)
+    if case == "large_keys":
+        flat["W_mem"] *= 250.0
+    else:
+        flat["W_q"] *= 200.0
+    flat["b_fc"][bc.cfg.end_token] = -1.0
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=6)
+    taps, pq_max, orig_step = {}, [0.0], oracle.attention_step
+    def spy(weights, *a, **k):                               # the largest |h . W_q| the fp64 decode sees
+        out = orig_step(weights, *a, **k)
+        pq_max[0] = max(pq_max[0], float(np.abs(out[3][-1][0] @ np.asarray(weights["W_q"], np.float64)).max()))
+        return out
+    oracle.attention_step = spy
+    try:
+        ot, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
+    finally:
+        oracle.attention_step = orig_step
+    if case == "large_keys":
+        assert np.abs(taps["keys"]).max(axis=(1, 2)).min() > 22.2      # |2 log2(e) k| > 64 somewhere in EVERY chunk's memory
+    else:
+        assert pq_max[0] > 25.0 and np.abs(taps["keys"]).max() < 22.0  # |2 log2(e) q| > 60 at some step, keys in range
+    bc.set_option("persist_taps", 1)
+    got = {}
+    for mcell in (1, 0):
+        bc.set_option("matrix_cell", mcell)
+        tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+        S = tok.shape[1]
+        got[mcell] = (tok.numpy().copy(), sc.numpy().copy(), bc.get_tensor("step_logits").reshape(S, B, W, 7).copy(),
+                      bc.get_tensor("parent_ids").reshape(S, B, W).copy(), bc.get_tensor("chunk_steps").astype(int))
+    assert np.isfinite(got[1][2][:1]).all() and got[1][0].shape == got[0][0].shape
+    same_order = 0
+    for b in range(B):
+        n = min(got[1][4][b], got[0][4][b])
+        if (got[1][3][:n, b] == got[0][3][:n, b]).all() and (got[1][0][b] == got[0][0][b]).all():
+            same_order += 1
+            assert np.abs(got[1][2][:n, b] - got[0][2][:n, b]).max() < TOL, (case, b)
+    assert same_order >= B - 2, (case, same_order)
+    n_cmp = 0
+    for b in range(B):
+        n = min(got[1][4][b], ot.shape[1])
+        if (got[1][3][:n, b] == taps["parent_ids"][:n, b]).all():
+            n_cmp += 1
+            assert np.abs(got[1][2][:n, b] - taps["step_logits"][:n, b]).max() < TOL, (case, b)
+    assert n_cmp >= B - 3, (case, n_cmp)
+    bc.close()
+
+
 @pytest.mark.parametrize("wide", [1, 0])
 def test_chunks_never_interact_at_full_size(rv, wide):
     """Size-independent property at BASELINE's C3 size: a chunk decoded inside a 256-chunk slab (two rows per recurrence workgroup,

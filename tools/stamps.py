@@ -6,7 +6,8 @@ import torch
 import ravvent_basecaller_amd as rv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T_R = int(os.environ.get("RV_T_R", "300"))
-bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_R, max_event_len=30, max_output_len=48)
+bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, max_batch=B, max_raw_len=T_R, max_event_len=30, max_output_len=48,
+                   attention_type=os.environ.get("RV_ATT", "luong"), honor_attention_type=True)
 bc.init_random_weights(seed=22)
 raw, ev, _ = rv.synthetic.make_slab(B, T_R, 30, seed=0)
 x = (torch.from_numpy(raw).cuda(), torch.from_numpy(ev).cuda())
