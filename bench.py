@@ -139,7 +139,7 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent
     # calls of L - 1 varied letters: every chunk is longer than the merger's 25-letter overlap, so the read really is spliced and grows
     # (the round-2 weights emitted calls of <= 25 letters: 7.6 k alignments ran and the merged read stayed at 145 bases)
     bc.set_weights_flat(rv.weights.base_calling_weights(bc.cfg))
-    e = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True, pipelined_merge=pipelined, concurrent_slabs=concurrent)
+    e = rv.evaluator.PerformanceEvaluator(bc, pipelined_merge=pipelined, concurrent_slabs=concurrent)   # (fused post-processing: the default)
     e.run_slabs(raw[:slab], ev[:slab], nuc[:slab], chunk_size=slab)          # warm-up
     best = None
     for _ in range(3):
@@ -161,14 +161,16 @@ def read_level(rv, device, n_bases=49500, slab=1024, pipelined=False, concurrent
             "t_merge": round(best["t_merge"], 5), "total_processing": round(tp, 5)}
 
 
-def bahdanau_timing(rv, device, B, T_r, T_e, W, L, steps=10):
-    """north_star names Bahdanau attention (Decoder(attention_type='bahdanau'), basecaller.py:131-132): the same workload with
-    the additive score v . tanh(keys + W_q h) in the one-launch persistent decode (one exp + one rcp per key element:
-    transcendental-rate bound where Luong's dot product is FMA bound)."""
+def variant_timing(rv, device, B, T_r, T_e, W, L, what, steps=10, **ctor):
+    """The same workload on another model variant of the reference (untimed extra, own handle): `bahdanau` -- north_star names Bahdanau
+    attention (Decoder(attention_type='bahdanau'), basecaller.py:131-132): tanh scores on the vector ALU, everything else on the matrix
+    pipe; `enc3_dec2` -- the reference's best model family (three BiLSTM layers per encoder, two stacked decoder cells,
+    basecaller.py:85-91; accuracy_results_all.lambda.beam5.json).  Synchronous slabs with the decode launch timed alone, then streamed
+    through the asynchronous calls like the headline (10 slabs in flight; results identical)."""
     import gc
     import torch
-    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, attention_type="bahdanau", honor_attention_type=True,
-                       max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L, device=device)
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, honor_attention_type=True,
+                       max_batch=B, max_raw_len=T_r, max_event_len=T_e, max_output_len=L, device=device, **ctor)
     bc.init_random_weights(seed=22)
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=0)
     x = (torch.from_numpy(raw).to(bc.device), torch.from_numpy(ev).to(bc.device))
@@ -185,7 +187,6 @@ def bahdanau_timing(rv, device, B, T_r, T_e, W, L, steps=10):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     prof = bc.profile()
-    # ... and streamed through the asynchronous calls like the headline (10 slabs in flight; results identical)
     bc.set_option("profile", 0)
     bc.set_async_depth(10)
     for _ in bc.beam_search_stream((x for _ in range(10)), W, L):
@@ -199,7 +200,7 @@ def bahdanau_timing(rv, device, B, T_r, T_e, W, L, steps=10):
     gc.enable()
     bc.close()
     name = "dec_persist" if "dec_persist" in prof else "decode_graph"
-    return {"workload": "C3 shape, Bahdanau attention, " + ("one-launch persistent decode" if name == "dec_persist" else "per-step decode kernels in a hipGraph"),
+    return {"workload": f"C3 shape, {what}, " + ("one-launch persistent decode" if name == "dec_persist" else "per-step decode kernels in a hipGraph"),
             "ms_per_step": round(dt * 1e3, 4), "chunks_per_s": round(B / dt, 1), "decode_steps": int(tok.shape[1]),
             "decode_ms_per_launch": round(prof[name][0] / max(prof[name][1], 1), 4),
             "streamed": {"ms_per_step": round(dts * 1e3, 4), "chunks_per_s": round(B / dts, 1), "note": f"{4 * steps} slabs through the asynchronous calls, 10 in flight"}}
@@ -668,7 +669,9 @@ def main():
                 out["read_level"] = read_level(rv, local)
                 out["read_level_pipelined"] = read_level(rv, local, pipelined=True)
                 out["read_level_concurrent"] = read_level(rv, local, pipelined=True, concurrent=4)
-                out["bahdanau"] = bahdanau_timing(rv, local, B, T_r, T_e, W, L)
+                out["bahdanau"] = variant_timing(rv, local, B, T_r, T_e, W, L, "Bahdanau attention", attention_type="bahdanau")
+                out["enc3_dec2"] = variant_timing(rv, local, B, T_r, T_e, W, L, "encoder depth 3, two decoder cells, Luong attention",
+                                                  encoder_depth=3, decoder_depth=2, attention_type="luong")
             except Exception as e:
                 out["extras_error"] = repr(e)
         if not args.no_cpu_baseline and world == 1:

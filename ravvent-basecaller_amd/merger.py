@@ -159,16 +159,27 @@ class Merger():
         return out_s[:m.value].tobytes().decode("ascii"), out_p[:m.value].copy()
 
     def merge(self, nuc_pred_snippets) -> SeqLogitsPair:
+        """merger.py:155-248 through the C++ merge.  The list of pairs becomes the arrays of `merge_arrays` in a handful of vectorised
+        numpy calls -- one join of the strings, one concatenation of the per-base values -- not in a Python loop over the chunks
+        (round 3: 3.6 us per pair against 1.2 us for the merge itself)."""
         n = len(nuc_pred_snippets)
-        stride = max(1, max(len(s.seq) for s in nuc_pred_snippets))
-        bases = np.zeros((n, stride), np.uint8)
-        probs = np.zeros((n, stride), np.float32)
-        lengths = np.zeros(n, np.int32)
-        for i, s in enumerate(nuc_pred_snippets):
-            k = len(s.seq)
-            lengths[i] = k
-            if k:
-                bases[i, :k] = np.frombuffer(s.seq.encode("ascii"), np.uint8)
-                probs[i, :k] = np.asarray(s.logits, np.float32)
-        seq, lg = self.merge_arrays(bases, probs, lengths)
-        return SeqLogitsPair(seq=seq, logits=list(lg))
+        seqs = [s.seq for s in nuc_pred_snippets]
+        lengths = np.fromiter(map(len, seqs), np.int32, count=n)
+        total = int(lengths.sum())
+        stride = max(1, int(lengths.max(initial=0)))
+        flat_b = np.frombuffer("".join(seqs).encode("ascii"), np.uint8)
+        lg = [s.logits for s in nuc_pred_snippets]
+        if total and all(isinstance(x, np.ndarray) for x in lg):
+            flat_p = np.concatenate(lg).astype(np.float32, copy=False)
+        else:                                              # Python lists (the reference's form): one flattening pass
+            from itertools import chain
+            flat_p = np.fromiter(chain.from_iterable(lg), np.float32, count=total)
+        # position of every letter in the padded [n, stride] layout
+        starts = np.cumsum(lengths, dtype=np.int64) - lengths
+        dst = np.arange(total, dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64) * stride - starts, lengths)
+        bases = np.zeros(n * stride, np.uint8)
+        probs = np.zeros(n * stride, np.float32)
+        bases[dst] = flat_b
+        probs[dst] = flat_p
+        seq, out = self.merge_arrays(bases.reshape(n, stride), probs.reshape(n, stride), lengths)
+        return SeqLogitsPair(seq=seq, logits=out)

@@ -52,7 +52,7 @@ def test_config5_long_read_sharded_eight_ways(rv):
     # the C++ merger against the line-by-line restatement of merger.py on these 7.7 k real calls
     assert merger_oracle.merge(whole["nuc_preds"])[0] == merged
     # host post-processing (the reference's own sequence: tokens -> strings, scores -> probabilities) and the pipelined merge
-    host = rv.evaluator.PerformanceEvaluator(bc).run_slabs(raw, ev, nuc, bases_num=N_BASES, chunk_size=1024)
+    host = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=False).run_slabs(raw, ev, nuc, bases_num=N_BASES, chunk_size=1024)
     assert [s for s, _ in host["nuc_preds"]] == [s for s, _ in whole["nuc_preds"]] and host["merged_seq"] == merged
     piped = rv.evaluator.PerformanceEvaluator(bc, pipelined_merge=True).run_slabs(raw, ev, nuc, bases_num=N_BASES, chunk_size=1024)
     assert piped["merged_seq"] == merged

@@ -595,7 +595,7 @@ def test_early_finish_stops_the_loop(rv, oracle):
 def test_evaluator_call_sequence(rv):
     bc, _ = _mk(rv, max_batch=64)
     raw, ev, nuc = rv.synthetic.make_slab(150, 60, 10, seed=6, L=14)
-    res = rv.evaluator.PerformanceEvaluator(bc).run_slabs(raw, ev, nuc, chunk_size=64)
+    res = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=False).run_slabs(raw, ev, nuc, chunk_size=64)     # the reference's host sequence
     for key in ("bases_num", "samples_num", "t_data_loading", "t_predicting", "t_postprocessing", "t_merge",
                 "total", "total_processing"):        # ravvent_performance_evaluator.py:78-87
         assert key in res
@@ -746,7 +746,7 @@ def test_fused_postprocessing_matches_host_form(rv):
     for s, p, pr in zip(seqs, probs, probs_ref):
         assert len(p) == len(s) and np.abs(p - pr[:len(s)]).max(initial=0.0) < 1e-6
     ev1 = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=True).run_slabs(raw, ev, np.zeros((40, 24), np.int64), chunk_size=64)
-    ev0 = rv.evaluator.PerformanceEvaluator(bc).run_slabs(raw, ev, np.zeros((40, 24), np.int64), chunk_size=64)
+    ev0 = rv.evaluator.PerformanceEvaluator(bc, fused_postprocessing=False).run_slabs(raw, ev, np.zeros((40, 24), np.int64), chunk_size=64)
     assert [a for a, _ in ev1["nuc_preds"]] == [a for a, _ in ev0["nuc_preds"]]
     bc.close()
 
