@@ -158,6 +158,11 @@ struct DecState {
   // [8 waves][4 k-steps][2 parts][64 lanes][8 f16] (64 KB): wave w owns columns 16 w .. 16 w + 15, lane (n, kq) of k-step ks holds
   // T . W_q[32 ks + 8 kq + 0..7][16 w + n]; the A operand is the h half of the [ctx' | h] image (h 2^14): mx_qdescale = 2^-14 / T
   const uint16_t* Wq16; float mx_qdescale;
+  // Two decoder cells on the matrix pipe (depth == 2, mx_attention == 2).  Wc16 is then cell 0's product over [ctx' | h_1 | h_0]:
+  // [W_a ; A_h W_a ; U_0] [384][512] as [8 waves][48 (k-step, gate) pairs][2 parts][64 lanes][8 f16] (768 KB; rows divided by mx_uscale /
+  // 2^14 / 2^14, one power-of-two scale, mx_cdescale its inverse); W1c16 = cell 1's two products, [8 waves][32 pairs][2][64][8] (512 KB):
+  // pairs 0..15 = W_1 (input product on h_0), pairs 16..31 = U_1 (recurrent product on h_1), rows divided by 2^14, one scale (mx_c1descale)
+  const uint16_t* W1c16; float mx_c1descale;
   int attend_threads;     // 0: pick by slab size; 256 / 512: force that single-pass attend variant
   int part;               // sub-slab index (decode of one slab may run as up to 4 concurrent sub-slabs)
   long long* dbg_ts;      // diagnostic: [16] s_memtime stamps of block 0 at the phase boundaries of step 3

@@ -902,6 +902,10 @@ __host__ __device__ constexpr int part_floats(int W) { return 4 * W * RV_G > PER
 __host__ __device__ constexpr int mxc_nc(int W) { return W <= 5 ? 2 : 1; }
 constexpr int MXC_STATIC_LDS = 1024;     // static LDS of the matrix-pipe instantiations (bias, beam bookkeeping): the others keep ~8.7 KB of output layer
 __host__ __device__ constexpr int mxc_cache_floats(int W) { return (32 + 7 * mxc_nc(W)) * 512; }
+// two decoder cells on the matrix pipe: per step and wave 48 pairs of cell 0's product ([ctx' | h_1 | h_0] . [W_a ; A_h W_a ; U_0], K = 384) and
+// 16 of cell 1's recurrent product (h_1 . U_1) at the end of the step, 16 of cell 1's input product (h_0 . W_1) after cell 0's gates.  The
+// LDS that is left (W <= 5) keeps the first MXC2_CACHE of wave 0's 64 end-of-step pairs: wave 0 joins that stream 4.7 k cycles late
+constexpr int MXC2_CACHE = 32;
 constexpr int MXC_ZS = RV_G + 16;
 __host__ __device__ constexpr int part_floats_mxc(int W) { return W * MXC_ZS > PERSIST_MAX_NIT * 256 ? W * MXC_ZS : PERSIST_MAX_NIT * 256; }
 struct PersistLds {
@@ -918,7 +922,8 @@ struct PersistLds {
     part = o; o += mxc ? part_floats_mxc(W) : part_floats(W);     // cell-product partial sums [4][W][512] (end of step -> gates), then the attention
                                        // layer's h-part partial sums [16][W][128] (after the gates -> merge)
     ctxp = part;                       // context partial sums of the 8 waves [8][W][128]: one cell -> inside `part` (idle between
-    if (D > 1) { ctxp = o; o += 8 * W * RV_U; }   // the gates and the end of the step); two cells -> own space (`part` holds h . A_h then)
+    if (D > 1 && !mxc) { ctxp = o; o += 8 * W * RV_U; }   // the gates and the end of the step); two cells -> own space (`part` holds h . A_h then)
+    if (D > 1 && mxc) { ctxp = o; o += W * MXC_ZS; }      // two cells on the matrix pipe: h_1 . U_1 of the beams, [W][RV_G + 16] (`partU`)
     fold = o; o += mxc ? 1024 : 8 * 4 * 2 * 16 * 4;   // (mxc: only the query image, 2 parts x 1024 f16)   wave-private fold slab: 4 streams x 2 float4 x 16 lanes.  ctxp + fold also hold the
                                        // second cell's recurrent partial sums [3][W][512] between the end of a step and its gates
     hcT = o; if (!mxc) o += RV_U * WB;  // h of the top cell, k-major beam-minor (cell input rows 128..255, attention-layer input)
@@ -928,7 +933,7 @@ struct PersistLds {
     lg = o; o += WB * RV_MAX_VOCAB;
     h0T = o; cS1 = o; b1s = o;
     if (D > 1) {                       // StackedRNNCells, second cell (basecaller.py:85-91)
-      h0T = o; o += RV_U * WB;         // h of cell 0, k-major beam-minor (input of cell 1 and rows 128..255 of cell 0's product)
+      h0T = o; if (!mxc) o += RV_U * WB;   // h of cell 0, k-major beam-minor (input of cell 1 and rows 128..255 of cell 0's product); mxc: in `xim`
       cS1 = o; o += 2 * W * RV_U;
       b1s = o; o += RV_G;
     }
@@ -938,11 +943,11 @@ struct PersistLds {
       vat = o; o += RV_U;
     }
     xim = o;
-    if (mxc) o += 2048;                // [ctx' | h] of the beams as MFMA A fragments: [2 parts][32 k-blocks][8 slots][8] f16
+    if (mxc) o += D > 1 ? 3072 : 2048; // [ctx' | h] ([ctx' | h_1 | h_0] with two cells) of the beams as MFMA A fragments: [32 | 48 k-blocks][16 rows][8] f16
     wl16 = o;
     if (mxc) o += 4096;                // the output layer [W_fc ; A_h W_fc] as B fragments (DecState::Wl16, 16 KB): wave 0's logits
     wcache = o;
-    if (mxc) o += mxc_cache_floats(W);
+    if (mxc) o += D > 1 ? MXC2_CACHE * 512 : mxc_cache_floats(W);
     else if (persist_weight_cache(W, D)) o += 24 * RV_G;   // 24 rows of the cell kernel kept in LDS (48 KB): the last 8 rows of K groups 1-3
     total = o;
   }
@@ -958,10 +963,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   constexpr bool MX = ATT >= 2;            // the context on the matrix pipe (U' resident as f16 B fragments, alignments through an LDS image)
   constexpr bool MXS = ATT == 2 || ATT == 3;   // ... and the Luong scores (keys resident as f16 B fragments, query through an LDS image)
   constexpr bool MXC = ATT == 3 || ATT == 4;   // ... and the cell product [ctx' | h] . Wcat2 and the output layer (weights as B fragments: Wc16, Wl16)
+  constexpr bool MXC2 = MXC && D == 2;     // two decoder cells, every product on the matrix pipe
   constexpr int ZS = MXC ? MXC_ZS : RV_G;  // row stride of the gate pre-activations in `part`
-  constexpr int NC = mxc_nc(W);
-  constexpr int NR = (ATT == 3 && NIT <= 8) ? 5 : 0;   // T_m <= 256 leaves ~50 registers: waves 1-7 keep NR more (k-step, gate) pairs of their share there
-  static_assert(!MX || D == 1, "the matrix-pipe attention keeps its A fragments in `part` and `fold`: one decoder cell");
+  constexpr int NC = MXC2 ? 0 : mxc_nc(W);
+  constexpr int NR = (ATT == 3 && D == 1 && NIT <= 8) ? 5 : 0;   // T_m <= 256 leaves ~50 registers: waves 1-7 keep NR more (k-step, gate) pairs of their share there
+  static_assert(!MX || D == 1 || ATT == 3, "two decoder cells run either on packed FMAs (ATT 0) or with everything on the matrix pipe (ATT 3)");
   static_assert(NIT <= PERSIST_MAX_NIT && NIT * 256 <= (MXC ? part_floats_mxc(W) : part_floats(W)), "the alignment image (2 f16 parts x 32 NIT steps x 8 slots) must fit `part`");
   static_assert(2 * 1024 * sizeof(_Float16) /* query image: 2 parts x [16 k-blocks][8 slots][8] f16 */ <= (8 * 4 * 2 * 16 * 4) * sizeof(float), "the query image must fit `fold`");
   extern __shared__ __align__(16) float dsm[];
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   float* attT = dsm + L.attT;  float* zb = dsm + L.zb;  float* cS = dsm + L.cS;
   float* qp = dsm + L.qp;  float* part = dsm + L.part;  float* ctxp = dsm + L.ctxp;  float* hcT = dsm + L.hcT;  float* att = dsm + L.att;
   float* ml = dsm + L.ml;  float* mg = dsm + L.mg;  float* lg = dsm + L.lg;  float* fold = dsm + L.fold;
-  float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (spans ctxp + fold)
+  float* h0T = dsm + L.h0T;  float* cS1 = dsm + L.cS1;  float* b1s = dsm + L.b1s;  float* partU = ctxp;   // D == 2 only (FMA form: spans ctxp + fold)
   // output layer weights, transposed to [v][k] (rows padded to 132 floats: the 8-lane groups of two outputs then read different banks)
   constexpr int FCW = RV_U + 4;
   // (the matrix-pipe form takes the output layer from the Wl16 fragments: it only needs the bias here, and neither `qp` nor `att`)
@@ -1092,11 +1098,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
   }
   for (int i = tid; i < 2 * W * RV_U; i += NT) cS[i] = 0.f;
   for (int i = tid; i < (MXC ? W * ZS : 4 * W * RV_G); i += NT) part[i] = 0.f;
-  if (MXC) for (int i = tid; i < 2048; i += NT) dsm[L.xim + i] = 0.f;
+  if (MXC) for (int i = tid; i < (MXC2 ? 3072 : 2048); i += NT) dsm[L.xim + i] = 0.f;
   if (D > 1) {
-    for (int i = tid; i < RV_U * WB; i += NT) h0T[i] = 0.f;
+    if (!MXC) for (int i = tid; i < RV_U * WB; i += NT) h0T[i] = 0.f;
     for (int i = tid; i < 2 * W * RV_U; i += NT) cS1[i] = 0.f;
-    for (int i = tid; i < 3 * W * RV_G; i += NT) partU[i] = 0.f;
+    for (int i = tid; i < (MXC ? W * ZS : 3 * W * RV_G); i += NT) partU[i] = 0.f;
     b1s[tid] = bdec1[tid];
   }
   if (!MXC) {
@@ -1109,7 +1115,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     uint4* dst = reinterpret_cast<uint4*>(dsm + L.wl16);
     for (int i = tid; i < 1024; i += NT) dst[i] = src[i];
   }
-  if (MXC) {   // wave 0's 32 pairs, then the last NC pairs of waves 1-7: 2 KB each, in image order
+  if (MXC2) {  // the first MXC2_CACHE of wave 0's end-of-step pairs (cell 0's product, image order)
+    const uint4* src = reinterpret_cast<const uint4*>(d.Wc16);
+    uint4* dst = reinterpret_cast<uint4*>(wcache);
+    for (int i = tid; i < MXC2_CACHE * 128; i += NT) dst[i] = src[i];
+  } else if (MXC) {   // wave 0's 32 pairs, then the last NC pairs of waves 1-7: 2 KB each, in image order
     const uint4* src = reinterpret_cast<const uint4*>(d.Wc16);
     uint4* dst = reinterpret_cast<uint4*>(wcache);
     for (int i = tid; i < 32 * 128; i += NT) dst[i] = src[i];
@@ -1176,37 +1186,83 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     if constexpr (MXC) {
       // W * 128 (beam, unit) items on 512 threads: waves 0-1 take two (W = 5).  Both items' operands are read first, then both are
       // computed, then stored: the second item rides in the first one's LDS and transcendental latencies instead of doubling the phase.
-      constexpr int NITEM = (W * RV_U + NT - 1) / NT;
-      float z4[NITEM][4], cp[NITEM];
-      bool ok[NITEM];
+      // CELL 0: z = the end-of-step product of the PARENT beam + the token's row; CELL 1 (two cells): z = h_0 . W_1 of this beam (taken
+      // right before) + h_1 . U_1 of the parent beam (end of the previous step) + b_1.  h goes to its segment of the A-fragment image:
+      // one cell [ctx' | h]; two cells [ctx' | h_1 | h_0]; the top cell's h is the score query as well.
+      auto mxc_gates = [&](auto cell_tag) {
+        constexpr int CELL = decltype(cell_tag)::value;
+        constexpr bool TOP = CELL == D - 1;
+        constexpr int NITEM = (W * RV_U + NT - 1) / NT;
+        float* cst = CELL == 0 ? cS : cS1;
+        float z4[NITEM][4], cp[NITEM];
+        bool ok[NITEM];
 #pragma unroll
-      for (int it = 0; it < NITEM; ++it) {
-        const int idx = tid + it * NT;
-        ok[it] = idx < W * RV_U;                             // wave-uniform (128 items per beam, 64 lanes per wave)
-        const int w = ok[it] ? idx >> 7 : 0, u = idx & 127, pb = s_parent[w], tk = s_tok[w];
+        for (int it = 0; it < NITEM; ++it) {
+          const int idx = tid + it * NT;
+          ok[it] = idx < W * RV_U;                             // wave-uniform (128 items per beam, 64 lanes per wave)
+          const int w = ok[it] ? idx >> 7 : 0, u = idx & 127, pb = s_parent[w], tk = s_tok[w];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z4[it][g] = part[pb * ZS + g * RV_U + u] + zb[tk * RV_G + g * RV_U + u];
-        cp[it] = cS[cb * W * RV_U + pb * RV_U + u];
-      }
-#pragma unroll
-      for (int it = 0; it < NITEM; ++it) {
-        if (!ok[it]) continue;
-        const int idx = tid + it * NT, w = idx >> 7, u = idx & 127;
-        const float c2 = fmaf(rv_sigmoid(z4[it][1]), cp[it], rv_sigmoid(z4[it][0]) * rv_tanh(z4[it][2]));
-        const float hh = rv_sigmoid(z4[it][3]) * rv_tanh(c2);
-        cS[(cb ^ 1) * W * RV_U + idx] = c2;
-        {   // h as A fragments of the cell product: k = 128 + u, h 2^14 in two f16 parts
-          const float sv = hh * 16384.f;
-          const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-          _Float16* xq = xim + (((RV_U + u) >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
-          xq[0] = hi; xq[8] = lo;
+          for (int g = 0; g < 4; ++g) {
+            if constexpr (CELL == 0) z4[it][g] = part[pb * ZS + g * RV_U + u] + zb[tk * RV_G + g * RV_U + u];
+            else z4[it][g] = (part[w * ZS + g * RV_U + u] + partU[pb * ZS + g * RV_U + u]) + b1s[g * RV_U + u];
+          }
+          cp[it] = cst[cb * W * RV_U + pb * RV_U + u];
         }
-        if constexpr (MXS) {   // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
-          const float sv = (hh * LOG2E) * 16384.f;
-          const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-          _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
-          qa[0] = hi; qa[8] = lo;
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+          if (!ok[it]) continue;
+          const int idx = tid + it * NT, w = idx >> 7, u = idx & 127;
+          const float c2 = fmaf(rv_sigmoid(z4[it][1]), cp[it], rv_sigmoid(z4[it][0]) * rv_tanh(z4[it][2]));
+          const float hh = rv_sigmoid(z4[it][3]) * rv_tanh(c2);
+          cst[(cb ^ 1) * W * RV_U + idx] = c2;
+          {   // h as A fragments: h 2^14 in two f16 parts, k = 128 + u (top cell), 256 + u (cell 0 of two)
+            const float sv = hh * 16384.f;
+            const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+            _Float16* xq = xim + ((((TOP ? 1 : 2) * RV_U + u) >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
+            xq[0] = hi; xq[8] = lo;
+          }
+          if constexpr (MXS && TOP) {   // the score query as MFMA A fragments: [k-block u / 8][row mx_row(w) (+ 1: low part)][u % 8] f16 of h log2(e) 2^14
+            const float sv = (hh * LOG2E) * 16384.f;
+            const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+            _Float16* qa = reinterpret_cast<_Float16*>(fold) + ((u >> 3) * 16 + mx_row(w)) * 8 + (u & 7);
+            qa[0] = hi; qa[8] = lo;
+          }
         }
+      };
+      mxc_gates(std::integral_constant<int, 0>{});
+      if constexpr (MXC2) {
+        __syncthreads();
+        // ---- cell 1's input product z_1a = h_0(new) . W_1 on the matrix pipe: every wave its 16 units x 4 gates, K = 128 (the h_0 segment
+        //      of the image: k-steps 8..11), 16 pairs streamed from the W1c16 image through a window of 4; `part` (cell 0's z~, consumed by
+        //      the gates above) takes the result, rows = this step's beams
+        {
+          const int l16 = lane & 15, kq = lane >> 4;
+          const uint4* wimg = reinterpret_cast<const uint4*>(d.W1c16) + (size_t)wv * (32 * 128) + lane;
+          const _Float16* xa = xim + (kq * 16 + l16) * 8;
+          f4v acc[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+          uint4 bh[4], bl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { bh[i] = wimg[(2 * i) * 64]; bl[i] = wimg[(2 * i + 1) * 64]; }
+#pragma unroll
+          for (int p = 0; p < 16; ++p) {
+            const h8 a = *reinterpret_cast<const h8*>(xa + (8 + (p >> 2)) * 512);
+            acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, bl[p & 3]), acc[p & 3], 0, 0, 0);
+            acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, bh[p & 3]), acc[p & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 4 < 16) { bh[p & 3] = wimg[(2 * (p + 4)) * 64]; bl[p & 3] = wimg[(2 * (p + 4) + 1) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          constexpr int NI = W > 4 ? 2 : 1;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              if (kq + 4 * i < W) part[(kq + 4 * i) * ZS + RV_U * g + 16 * wv + l16] = (acc[g][2 * i] + acc[g][2 * i + 1]) * d.mx_c1descale;
+        }
+        __syncthreads();
+        mxc_gates(std::integral_constant<int, 1>{});
       }
     } else
     for (int idx = tid; idx < W * RV_U; idx += NT) {       // K-group sums in fixed order, gate math, cell update
@@ -1230,7 +1286,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
       }
     }
     __syncthreads();
-    if (D > 1) {
+    if (D > 1 && !MXC) {
       // ---- second cell: z_1 = h_0(new) . W_1 + [h_1(prev) . U_1 of the parent beam, taken at the end of the previous step] + b_1
       {
         const int c4 = tid & 127, kg = tid >> 7;           // 32 rows of W_1 per K group
@@ -1335,7 +1391,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     }
     RV_STAMP(d, step, 2);
     // ================= (two cells) attention layer, h part: h . A_h ; thread = (4 columns, 1 of 16 K groups of 8 rows), one batch
-    if (D > 1) {
+    if (D > 1 && !MXC) {
       const int d4 = tid & 31, kg = tid >> 5;
       f2 acc[W][2];
 #pragma unroll
@@ -1796,7 +1852,71 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
     // ================= next step's cell product on THIS step's beams: z~[w] = [attention_w | h_w] . Wcat (the beam step above
     //   only decides which z~ each new beam inherits).  thread = (4 gate columns c4, K group kg); waves 1-7 start at once,
     //   wave 0 joins after the beam step, so K group 0 (waves 0-1) is the short one: rows 0-39 | 40-111 | 112-183 | 184-255.
-    if constexpr (MXC) {
+    if constexpr (MXC2) {
+      // Two cells on the matrix pipe.  End of the step, on THIS step's beams (the beam step only decides which rows each new beam inherits):
+      //   cell 0's next product  z~_0 = [ctx' | h_1 | h_0] . [W_a ; A_h W_a ; U_0]   (K = 384: jobs 0..47, pair j = 4 ks + g of the Wc16 image)
+      //   cell 1's recurrent one z~_1 = h_1 . U_1                                     (K = 128: jobs 48..63, pairs 16..31 of the W1c16 image)
+      // -- the attention vector never exists: its h_1 . A_h half is folded into cell 0's rows 128..255 and into the output layer at
+      // load time, its context half is the ctx' segment.  Wave wv owns units 16 wv .. 16 wv + 15 of all four gates of both products
+      // (64 jobs of 2 KB); wave 0 -- output layer and beam step first -- finds its first MXC2_CACHE jobs in LDS.
+      if (step + 1 < steps) {
+        RV_STAMP_W1(d, step, 12);
+        const int l16 = lane & 15, kq = lane >> 4;
+        const uint4* w0img = reinterpret_cast<const uint4*>(d.Wc16) + (size_t)wv * (48 * 128) + lane;
+        const uint4* w1img = reinterpret_cast<const uint4*>(d.W1c16) + (size_t)wv * (32 * 128) + 16 * 128 + lane;
+        const _Float16* xa = xim + (kq * 16 + l16) * 8;
+        constexpr int NI = W > 4 ? 2 : 1, NB = 4;
+        f4v acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+        auto src = [&](int j, int q) -> uint4 { return j < 48 ? w0img[(2 * j + q) * 64] : w1img[(2 * (j - 48) + q) * 64]; };
+        auto mm = [&](int j, const uint4& vh, const uint4& vl) {
+          const int ks = j < 48 ? (j >> 2) : 4 + ((j - 48) >> 2), g = j & 3;      // h_1 . U_1 reads the h_1 segment: k-steps 4..7
+          const h8 a = *reinterpret_cast<const h8*>(xa + ks * 512);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vl), acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, vh), acc[g], 0, 0, 0);
+        };
+        auto flush = [&](float* dst, float scale) {         // C/D: lane (column l16, kq): registers 0 + 1 = beam kq, 2 + 3 = beam kq + 4
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              if (kq + 4 * i < W) dst[(kq + 4 * i) * ZS + RV_U * g + 16 * wv + l16] = (acc[g][2 * i] + acc[g][2 * i + 1]) * scale;
+            acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+          }
+        };
+        auto stream = [&](auto first_tag) {
+          constexpr int J0 = decltype(first_tag)::value;    // jobs J0..63 come from L2 through a window of NB
+          uint4 bh[NB], bl[NB];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) { bh[i] = src(J0 + i, 0); bl[i] = src(J0 + i, 1); }
+          if constexpr (J0 > 0) {                            // (wave 0) the LDS-resident jobs first: the first requests are in flight meanwhile
+            const uint4* wc = reinterpret_cast<const uint4*>(wcache) + lane;
+            uint4 fh = wc[0], fl = wc[64];
+#pragma unroll
+            for (int j = 0; j < J0; ++j) {
+              uint4 nh = fh, nl = fl;
+              if (j + 1 < J0) { nh = wc[(2 * (j + 1)) * 64]; nl = wc[(2 * (j + 1) + 1) * 64]; }
+              mm(j, fh, fl);
+              fh = nh; fl = nl;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int j = J0; j < 64; ++j) {
+            mm(j, bh[(j - J0) % NB], bl[(j - J0) % NB]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + NB < 64) { bh[(j - J0) % NB] = src(j + NB, 0); bl[(j - J0) % NB] = src(j + NB, 1); }
+            if (j == 47) flush(part, d.mx_cdescale);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          flush(partU, d.mx_c1descale);
+        };
+        if (wv == 0) stream(std::integral_constant<int, MXC2_CACHE>{});
+        else stream(std::integral_constant<int, 0>{});
+        RV_STAMP_W1(d, step, 13);
+      }
+    } else if constexpr (MXC) {
       // Matrix pipe: z~ [beams x 512] = x [beams x 256] . Wcat2 as split-f16 MFMAs.  Wave wv owns units 16 wv .. 16 wv + 15 of all
       // four gates over the whole K (no partial sums to merge): 32 (k-step, gate) pairs, each one B fragment pair (high, low
       // part; 2 KB per wave) streamed from the Wc16 image through a rolling window of NB pairs, the last NC pairs from LDS.  A = the
@@ -2058,6 +2178,7 @@ template <int W>
 static void launch_persist_w(const DecState& d, const float* Wcat, const float* Wtok, const float* bdec,
                              const float* Wcat1, const float* bdec1, const float* Nh, hipStream_t s) {
   if constexpr (W <= 5) {
+    if (d.depth > 1 && d.mx_attention == 2) { launch_persist_wd<W, 2, 3>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }   // two cells, everything on the matrix pipe
     if (d.depth > 1) { launch_persist_wd<W, 2, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s); return; }
   }
   if (d.attention == 1 && d.mx_attention == 2) launch_persist_wd<W, 1, 4>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);   // Bahdanau: scores on the VALU, the rest on the matrix pipe
@@ -2067,7 +2188,7 @@ static void launch_persist_w(const DecState& d, const float* Wcat, const float* 
   else launch_persist_wd<W, 1, 0>(d, Wcat, Wtok, bdec, Wcat1, bdec1, Nh, s);
 }
 bool dec_persist_supported(const DecState& d) {
-  const int att_form = d.attention == 1 ? (d.depth == 1 && d.mx_attention == 2 ? 4 : 1) : (d.depth == 1 && d.mx_attention == 2 ? 3 : 0);
+  const int att_form = d.attention == 1 ? (d.depth == 1 && d.mx_attention == 2 ? 4 : 1) : (d.depth <= 2 && d.mx_attention == 2 ? 3 : 0);
   if (sizeof(float) * PersistLds(d.W, d.depth > 1 ? 2 : 1, att_form).total + (att_form >= 3 ? MXC_STATIC_LDS : 10 * 1024) > 160 * 1024) return false;   // dynamic + static LDS
   return (d.attention == 0 || (d.attention == 1 && d.depth == 1)) && d.depth <= 2 && d.W <= (d.depth > 1 ? 5 : 8) && d.Tm <= 352 && !d.step_align && (!d.greedy || d.W == 1);
 }
@@ -2175,6 +2296,9 @@ static hipError_t configure_w() {
   opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 1, 4>), sizeof(float) * PersistLds(W, 1, 4).total);
   opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 1, 4>), sizeof(float) * PersistLds(W, 1, 4).total);
   if constexpr (W <= 5) {
+    opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2, 3>), sizeof(float) * PersistLds(W, 2, 3).total);
+    opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2, 3>), sizeof(float) * PersistLds(W, 2, 3).total);
+    opt3(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 2, 3>), sizeof(float) * PersistLds(W, 2, 3).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 2, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 8, 2>), sizeof(float) * PersistLds(W, 2).total);
     opt(reinterpret_cast<const void*>(&k_dec_persist<W, 11, 2>), sizeof(float) * PersistLds(W, 2).total);

@@ -79,6 +79,8 @@ struct RvContext {
   uint16_t* d_Wl16 = nullptr;               // derived (one decoder cell): [W_fc ; A_h W_fc] as MFMA B fragments (DecState::Wl16)
   uint16_t* d_Wq16 = nullptr;               // derived (Bahdanau, one decoder cell): W_q as MFMA B fragments (DecState::Wq16)
   float mx_qdescale = 1.f;
+  uint16_t* d_W1c16 = nullptr;              // derived (two decoder cells): [W_1 | U_1] as MFMA B fragments (DecState::W1c16)
+  float mx_c1descale = 1.f;
   float mx_kscale = 1.f, mx_uscale = 1.f;   // powers of two from the bounds of [keys | U'] = enc_out . Wmp (set by rv_load_weights)
   uint16_t* d_Ua = nullptr;                 // derived: recurrent kernels as MFMA A fragments (two f16 parts) + row factors, [enc][layer][dir][RV_UA_SLOT]
   uint16_t* d_Wx16 = nullptr;               // derived: input kernels of encoder layers >= 1, both directions, as the split GEMM's B slabs, [enc][layer-1][RV_WX16_SLOT]
@@ -615,9 +617,10 @@ int record_slab(RvContext* h, const float* xr, const float* xe, bool host_in, in
   d.chunk_steps = nullptr;
   // (sizes the decode's LDS)  Luong: 1 = scores and context on the matrix pipe, 2 = the cell product and the output layer too; Bahdanau: 2 = the
   // context, the processed query, the cell product and the output layer on the matrix pipe (the tanh scores stay on the VALU), else packed FMAs
-  d.mx_attention = (h->opt_mx_att && d.depth == 1) ? (h->opt_mx_cell ? 2 : (c.attention == RV_ATT_LUONG ? 1 : 0)) : 0;
+  // Two cells (Luong): 2 = every product of both cells on the matrix pipe, else packed FMAs.
+  d.mx_attention = (h->opt_mx_att && d.depth <= 2) ? (h->opt_mx_cell ? 2 : (c.attention == RV_ATT_LUONG && d.depth == 1 ? 1 : 0)) : 0;
   d.Wc16 = h->d_Wc16; d.mx_cdescale = h->mx_cdescale; d.Wl16 = h->d_Wl16; d.mx_ldescale = h->mx_ldescale;
-  d.Wq16 = h->d_Wq16; d.mx_qdescale = h->mx_qdescale;
+  d.Wq16 = h->d_Wq16; d.mx_qdescale = h->mx_qdescale; d.W1c16 = h->d_W1c16; d.mx_c1descale = h->mx_c1descale;
   h->lpersist = (persist_ok && dec_persist_supported(d)) ? 1 : 0;
   if (persist_ok && !h->lpersist) return fail(h, RV_ESTATE, "internal: persistent decode predicate mismatch");
   if (h->lpersist) { nsplit = 1; d.chunk_steps = h->d_chunk_steps; }
@@ -874,7 +877,7 @@ int create_child(RvContext* p, RvContext** out) {
   h->d_w = p->d_w; h->n_w = p->n_w;
   h->d_WmemT = p->d_WmemT; h->d_Up = p->d_Up; h->d_Wp = p->d_Wp; h->d_Wsb = p->d_Wsb; h->d_Wh = p->d_Wh; h->d_Ua = p->d_Ua;
   h->d_Wx16 = p->d_Wx16; h->d_bx2 = p->d_bx2; h->d_Wmp = p->d_Wmp; h->d_Wcat2 = p->d_Wcat2; h->d_Nh = p->d_Nh; h->d_Wmp16 = p->d_Wmp16; h->d_Wc16 = p->d_Wc16; h->d_Wl16 = p->d_Wl16;
-  h->d_Wq16 = p->d_Wq16;
+  h->d_Wq16 = p->d_Wq16; h->d_W1c16 = p->d_W1c16;
   h->d_WcatT = p->d_WcatT;
   bind_weights(h);
   const int rc = alloc_slab_buffers(h);
@@ -888,7 +891,7 @@ void sync_child(RvContext* k, const RvContext* p) {
   k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
   k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
   k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->mx_ldescale = p->mx_ldescale; k->opt_tail_wave = p->opt_tail_wave;
-  k->mx_qdescale = p->mx_qdescale;
+  k->mx_qdescale = p->mx_qdescale; k->mx_c1descale = p->mx_c1descale;
   k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
   k->opt_taps = 0; k->opt_ptaps = 0;      // debug taps belong to the synchronous calls
   k->inflight_hint = p->inflight_hint;
@@ -954,7 +957,8 @@ int rv_create(const RvConfig* cfg, rv_handle* out) {
   TRY(dalloc(h, &h->d_WcatT, (size_t)c.dec_depth * RV_G * RV_E));
   TRY(dalloc(h, &h->d_Wmp, (size_t)RV_E * RV_E));
   TRY(dalloc(h, &h->d_Wmp16, RV_WMP16_SLOT));
-  TRY(dalloc(h, &h->d_Wc16, (size_t)2 * RV_E * RV_G));
+  TRY(dalloc(h, &h->d_Wc16, (size_t)2 * 3 * RV_U * RV_G));      // (two cells: 384 rows)
+  if (c.dec_depth == 2) TRY(dalloc(h, &h->d_W1c16, (size_t)2 * RV_E * RV_G));
   TRY(dalloc(h, &h->d_Wl16, (size_t)2 * RV_E * 16));
   TRY(dalloc(h, &h->d_Wq16, (size_t)2 * RV_U * RV_U));
   TRY(dalloc(h, &h->d_Wcat2, (size_t)RV_E * RV_G));
@@ -1196,19 +1200,23 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
       for (int n = 0; n < RV_E; ++n) { const float f = std::ldexp(1.0f, -14) / cs[n]; memcpy(&img[(size_t)2 * RV_E * RV_E + 2 * n], &f, 4); }
       HIPCHK(h, hipMemcpy(h->d_Wmp16, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    if (h->cfg.dec_depth == 1) {
-      // attention = h . A_h + ctx'; its h part is folded into what consumes the attention vector (products in double):
-      // next cell input  [ctx' | h] . [W_a ; U + A_h W_a],  logits  ctx' . W_fc + h . (A_h W_fc) + b
+    if (h->cfg.dec_depth <= 2) {
+      // attention = h . A_h + ctx' (h = the top cell's output); its h part is folded into what consumes the attention vector (products in double):
+      //   one cell : next cell input  [ctx' | h] . [W_a ; U + A_h W_a],                 logits  ctx' . W_fc + h . (A_h W_fc) + b
+      //   two cells: cell 0's input   [ctx' | h_1 | h_0] . [W_a ; A_h W_a ; U_0],       logits  ctx' . W_fc + h_1 . (A_h W_fc) + b
       const int V = h->cfg.vocab;
+      const bool two = h->cfg.dec_depth == 2;
+      const int KR = two ? 3 * RV_U : RV_E;                 // rows of cell 0's folded kernel
       const size_t wa = (size_t)(h->dec[0].W - h->d_w) + (size_t)V * RV_G, uo = (size_t)(h->dec[0].U - h->d_w);
       const size_t ah = (size_t)(h->W_att - h->d_w), fc = (size_t)(h->W_fc - h->d_w);
-      std::vector<float> w2((size_t)RV_E * RV_G), nh((size_t)RV_U * RV_MAX_VOCAB, 0.f);
+      std::vector<float> w2((size_t)KR * RV_G), nh((size_t)RV_U * RV_MAX_VOCAB, 0.f);
       for (int i = 0; i < RV_U; ++i)
         for (int n = 0; n < RV_G; ++n) {
           w2[(size_t)i * RV_G + n] = blob[wa + (size_t)i * RV_G + n];
-          double acc = blob[uo + (size_t)i * RV_G + n];
+          double acc = two ? 0.0 : (double)blob[uo + (size_t)i * RV_G + n];
           for (int j = 0; j < RV_U; ++j) acc += (double)blob[ah + (size_t)i * RV_U + j] * (double)blob[wa + (size_t)j * RV_G + n];
           w2[(size_t)(RV_U + i) * RV_G + n] = (float)acc;
+          if (two) w2[(size_t)(2 * RV_U + i) * RV_G + n] = blob[uo + (size_t)i * RV_G + n];
         }
       for (int i = 0; i < RV_U; ++i)
         for (int v = 0; v < V; ++v) {
@@ -1216,21 +1224,22 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
           for (int j = 0; j < RV_U; ++j) acc += (double)blob[ah + (size_t)i * RV_U + j] * (double)blob[fc + (size_t)j * V + v];
           nh[(size_t)i * V + v] = (float)acc;
         }
-      HIPCHK(h, hipMemcpy(h->d_Wcat2, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (!two) HIPCHK(h, hipMemcpy(h->d_Wcat2, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));     // (the packed-FMA form of one cell)
       HIPCHK(h, hipMemcpy(h->d_Nh, nh.data(), nh.size() * sizeof(float), hipMemcpyHostToDevice));
       {   // the same kernel for the matrix-pipe cell product (DecState::Wc16): rows divided by the factor their input's f16 image
           // carries (exact: powers of two), one power-of-two scale for the tensor, two f16 parts in B-fragment order per wave
         auto xs = [&](int k) { return k < RV_U ? h->mx_uscale : 16384.f; };
         float mx = 0.f;
-        for (int k = 0; k < RV_E; ++k)
+        for (int k = 0; k < KR; ++k)
           for (int n = 0; n < RV_G; ++n) mx = std::max(mx, std::fabs(w2[(size_t)k * RV_G + n] / xs(k)));
         int ex = 0;
         if (mx > 0.f && std::isfinite(mx)) std::frexp(mx, &ex);
         const float T = std::ldexp(1.0f, 14 - ex);
         h->mx_cdescale = 1.0f / T;
-        std::vector<uint16_t> img((size_t)2 * RV_E * RV_G);
+        const int NP = KR / 8;                              // (k-step, gate) pairs per wave: 32, or 48 with two cells
+        std::vector<uint16_t> img((size_t)2 * KR * RV_G);
         for (int wv = 0; wv < 8; ++wv)
-          for (int pr = 0; pr < 32; ++pr)
+          for (int pr = 0; pr < NP; ++pr)
             for (int ln = 0; ln < 64; ++ln)
               for (int j = 0; j < 8; ++j) {
                 const int ks = pr >> 2, g = pr & 3, k = 32 * ks + 8 * (ln >> 4) + j, n = RV_U * g + 16 * wv + (ln & 15);
@@ -1238,10 +1247,33 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
                 const _Float16 hi = (_Float16)v;
                 const _Float16 lo = (_Float16)(v - (float)hi);
                 uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
-                img[(((((size_t)wv * 32 + pr) * 2 + 0) * 64) + ln) * 8 + j] = hb;
-                img[(((((size_t)wv * 32 + pr) * 2 + 1) * 64) + ln) * 8 + j] = lb;
+                img[(((((size_t)wv * NP + pr) * 2 + 0) * 64) + ln) * 8 + j] = hb;
+                img[(((((size_t)wv * NP + pr) * 2 + 1) * 64) + ln) * 8 + j] = lb;
               }
         HIPCHK(h, hipMemcpy(h->d_Wc16, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (two) {   // cell 1's kernels on h_0 (W_1) and on h_1 (U_1): DecState::W1c16, rows divided by the 2^14 their inputs' images carry
+          const size_t w1 = (size_t)(h->dec[1].W - h->d_w), u1 = (size_t)(h->dec[1].U - h->d_w);
+          float m1 = 0.f;
+          for (size_t i = 0; i < (size_t)RV_U * RV_G; ++i) m1 = std::max(m1, std::max(std::fabs(blob[w1 + i]), std::fabs(blob[u1 + i])) / 16384.f);
+          int e1 = 0;
+          if (m1 > 0.f && std::isfinite(m1)) std::frexp(m1, &e1);
+          const float T1 = std::ldexp(1.0f, 14 - e1);
+          h->mx_c1descale = 1.0f / T1;
+          std::vector<uint16_t> i1((size_t)2 * RV_E * RV_G);
+          for (int wv = 0; wv < 8; ++wv)
+            for (int pr = 0; pr < 32; ++pr)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                  const int ks = (pr & 15) >> 2, g = pr & 3, k = 32 * ks + 8 * (ln >> 4) + j, n = RV_U * g + 16 * wv + (ln & 15);
+                  const float v = (blob[(pr < 16 ? w1 : u1) + (size_t)k * RV_G + n] / 16384.f) * T1;
+                  const _Float16 hi = (_Float16)v;
+                  const _Float16 lo = (_Float16)(v - (float)hi);
+                  uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                  i1[(((((size_t)wv * 32 + pr) * 2 + 0) * 64) + ln) * 8 + j] = hb;
+                  i1[(((((size_t)wv * 32 + pr) * 2 + 1) * 64) + ln) * 8 + j] = lb;
+                }
+          HIPCHK(h, hipMemcpy(h->d_W1c16, i1.data(), i1.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         // the output layer on the same [ctx' | h] image: logits = ctx' . W_fc + h . (A_h W_fc) + b_fc; columns >= V are zero
         auto wl = [&](int k, int v) -> float {
           if (v >= V) return 0.f;
@@ -1266,7 +1298,7 @@ int rv_load_weights(rv_handle h, const float* blob, size_t n_floats) {
               li[(((size_t)ks * 2 + 1) * 64 + ln) * 8 + j] = lb;
             }
         HIPCHK(h, hipMemcpy(h->d_Wl16, li.data(), li.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        {   // Bahdanau's query layer W_q [128][128] for the matrix pipe (DecState::Wq16): one power-of-two scale, two f16 parts, per-wave B fragments
+        if (!two) {   // Bahdanau's query layer W_q [128][128] for the matrix pipe (DecState::Wq16): one power-of-two scale, two f16 parts, per-wave B fragments
           const size_t qo = (size_t)(h->W_q - h->d_w);
           float mq = 0.f;
           for (size_t i = 0; i < (size_t)RV_U * RV_U; ++i) mq = std::max(mq, std::fabs(blob[qo + i]));

@@ -699,6 +699,59 @@ def test_maximum_shapes_against_c_port(rv, oracle, W, weights):
     bc.close()
 
 
+@pytest.mark.parametrize("W,Tr,Te", [(5, 300, 30), (3, 200, 30), (1, 40, 9), (5, 60, 12)])
+def test_two_decoder_cells_on_the_matrix_pipe(rv, oracle, W, Tr, Te):
+    """The reference's enc3/dec2 family (StackedRNNCells of two LSTMCells, basecaller.py:85-91) on the persistent decode in its two forms:
+    the default since round 4 -- every product of both cells on the matrix pipe (cell 0 over [ctx' | h_1 | h_0] with the attention
+    layer's h part folded in, cell 1's input product right after cell 0's gates, its recurrent product at the end of the step; split-f16
+    operands) -- and packed fp32 FMAs (option matrix_cell = 0), against each other, the per-step kernels and the fp64 oracle: tokens,
+    beam ids and parents identical, per-step logits within 1e-4 of fp64 and within 2e-5 of each other, at the three memory-length
+    variants of the kernel, with a chunk that is mostly padding; greedy search too."""
+    B, L = 7, 14
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, "joint", 0.0, encoder_depth=3, decoder_depth=2, max_batch=B,
+                       max_raw_len=Tr, max_event_len=Te)
+    flat = rv.weights.init_weights(bc.cfg, seed=60 + W, gain=1.5)
+    flat["b_fc"][bc.cfg.end_token] = 0.3
+    flat["dec_cells.1.W"][:, 9] *= 8.0; flat["dec_cells.1.U"][5, :] *= 1e-3; flat["dec_cells.0.U"][:, 200] *= 6.0     # outliers in the three split images
+    bc.set_weights_flat(flat)
+    w = rv.weights.flat_to_nested(bc.cfg, flat)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=W, max_raw_pad=min(15, Tr - 1), max_event_pad=min(10, Te - 1))
+    raw[2, Tr // 3:] = 0.0
+    bc.set_option("persist_taps", 1)
+    bc.set_option("profile", 1)
+    got = {}
+    for form, (persist, mcell) in {"mx": (1, 1), "fma": (1, 0), "steps": (0, 1)}.items():
+        bc.set_option("persistent_decode", persist); bc.set_option("matrix_cell", mcell)
+        bc.reset_profile()
+        tok, sc = bc.beam_search_prediction((raw, ev), W, L)
+        assert ("dec_persist" in bc.profile()) == bool(persist)
+        S = tok.shape[1]
+        got[form] = [tok.numpy().copy(), sc.numpy().copy()]
+        if persist:
+            got[form] += [bc.get_tensor("chunk_steps").astype(int), bc.get_tensor("step_logits").reshape(S, B, W, 7).copy(),
+                          bc.get_tensor("step_ids").reshape(S, B, W).copy(), bc.get_tensor("parent_ids").reshape(S, B, W).copy()]
+    taps = {}
+    otok, osc = oracle.beam_search(w, bc.cfg.oracle_cfg(), raw, ev, W, L, dtype=np.float64, taps=taps)
+    for form in ("mx", "fma", "steps"):
+        assert got[form][0].shape == otok.shape and (got[form][0] == otok).all() and np.abs(got[form][1] - osc).max() < TOL, form
+    assert (got["mx"][2] == got["fma"][2]).all()
+    for form in ("mx", "fma"):
+        tok, sc, cs, lg, ids, par = got[form]
+        for b in range(B):
+            n = cs[b]
+            assert np.abs(lg[:n, b] - taps["step_logits"][:n, b]).max() < TOL, (form, b)
+            assert (ids[:n, b] == taps["step_ids"][:n, b]).all() and (par[:n, b] == taps["parent_ids"][:n, b]).all(), (form, b)
+    for b in range(B):
+        n = got["mx"][2][b]
+        assert np.abs(got["mx"][3][:n, b] - got["fma"][3][:n, b]).max() < 2e-5, b
+    for mcell in (1, 0):
+        bc.set_option("persistent_decode", 1); bc.set_option("matrix_cell", mcell)
+        g, glg = bc.greedy_search_prediction((raw, ev), L)
+        og, olg = oracle.greedy_search(w, bc.cfg.oracle_cfg(), raw, ev, L)
+        assert g.shape == og.shape and (g.numpy() == og).all() and np.abs(glg.numpy() - olg).max() < TOL, mcell
+    bc.close()
+
+
 @pytest.mark.parametrize("dec_depth,enc_depth", [(2, 3), (3, 2)])
 def test_stacked_decoder_cells(rv, oracle, dec_depth, enc_depth):
     """decoder_depth > 1 (StackedRNNCells, basecaller.py:85-91): the reference's enc3/dec2 model family."""
