@@ -24,7 +24,7 @@ LIMITS = {
     r"k_dec_persistILi5ELi8ELi1ELi3E": 0,        # R, the same
     r"k_dec_persistILi5ELi11ELi1ELi4E": 192,     # C3 with Bahdanau scores on the VALU and everything else on the matrix pipe, the Bahdanau default since round 4: 176 B today,
                                                  # of which the step loop touches 56 (three U' fragments reloaded in the context phase); the rest is the prologue's (keys -> 2^k')
-    r"k_dec_persistILi5ELi8ELi1ELi4E": 64,       # R, the same (60 B today: single registers of the unrolled score loop)
+    r"k_dec_persistILi5ELi8ELi1ELi4E": 96,       # R, the same (60-76 B: single registers of the unrolled score loop)
     r"k_dec_persistILi5ELi11ELi2ELi3E": 96,      # C3 with two decoder cells on the matrix pipe, the enc3/dec2 default since round 4 (80 B today: five U' fragments reloaded in the context phase)
     r"k_dec_persistILi5ELi8ELi2ELi3E": 0,        # R, the same
     r"k_lstm_rec_projILi2ELi[012]EE": 0,         # C3 fused recurrence + projection (f32, split-bf16 and split-f16 MFMA forms)
