@@ -1,11 +1,13 @@
 """Analyse a rocprofv3 --kernel-trace CSV of `bench.py --steps K --warmup W` (asynchronous calls): the TIMED REGION is the span of
 decode launches W .. W+K-1 (the run also holds the warm-up, an isolated per-kernel pass and a synchronous pass); per-kernel launch
 spans inside it, how many kernels are in flight, and the workgroup demand against the chip's 256 CUs.
-Usage: trace_overlap.py <kernel_trace.csv> [K] [W]"""
+Usage: trace_overlap.py <kernel_trace.csv> [K] [W] [depth]   (depth given = the round-4 bench: the timed region is followed by an untimed
+streamed pass of depth + K steps with events around the decode, then the isolated pass of synchronous calls)"""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20     # the driver's command: --steps 20 --warmup 5
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+D = int(sys.argv[4]) if len(sys.argv) > 4 else None
 ev = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -35,6 +37,6 @@ for t, d, w in pts:
     dt = (t - last) / 1e6; hist[cur] += dt; dsum += dt * min(dem, 256) / 256; cur += d; dem += w; last = t
 print("kernels in flight -> ms:", {k: round(v, 2) for k, v in sorted(hist.items())})
 print(f"workgroup demand (each launch capped at 256 CUs, sum capped at the chip) averages {100 * dsum / span:.0f} % of the chip")
-iso = [x for x in dec[W + K:W + K + 10]]
+iso = [x for x in (dec[W + K:W + K + 10] if D is None else dec[W + K + D + K:W + K + D + K + 10])]
 if iso:
     print(f"isolated pass (synchronous calls, the launch alone): k_dec_persist avg {sum((e - s) for s, e, _, _ in iso) / len(iso) / 1e6:.4f} ms over {len(iso)} launches")
