@@ -287,6 +287,7 @@ __global__ __launch_bounds__(384) void k_gemm_mem_split3(const float* __restrict
     for (int m = 0; m < 2; ++m) {
       const int row = tile * 128 + 32 * wave + 16 * m + l16;      // C/D map of the transposed tile: column = lane % 16 = row of C,
       if (row < M && !(dbg & 1)) {                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
+        // (pairing the column tiles into whole-line stores, as k_gemm_ws does, measured no gain here: 0.052-0.054 ms either way)
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
           const int col = cb * RV_E + 16 * nt + 4 * q;
@@ -407,20 +408,43 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // Epilogue.  C/D map of the transposed tile: lane (l16 = row of C, q) holds columns 16 nt + 4 q + 0..3 -- a store instruction of one
+    // column tile would write 64 bytes to each of 16 rows (half cache lines, rows 4 KB apart).  Two column tiles are paired instead:
+    // lanes l16 and l16 ^ 8 swap one tile each (DPP row_ror:8), so that an instruction writes the 32 columns of the pair -- one whole 128-byte
+    // line -- to each of 8 rows: half as many write requests, all of them full lines (round 4: 0.147 -> 0.135 ms on the C3 projection).
+    // (Tried with it and dropped: whole-line A loads by the same exchange, the weight image in the matching k order -- parity-identical, but
+    //  52 B of scratch at twelve waves, 0.165 ms; eight waves 0.154-0.163.  Ablations of this kernel, tools/gemm_ab.py: without the stores
+    //  0.105 ms, without the A loads 0.097, without either 0.082, and with a quarter of the MFMAs and no LDS reads still 0.145: the launch is
+    //  bound by its memory side -- 394 MB at 2.7-2.9 TB/s where a plain fill of the 315 MB output runs at 6.7 TB/s.)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const int row = t * 32 + 16 * m + l16;                        // C/D map of the transposed tile: column = lane % 16 = row of C,
-#ifdef RV_WS_NOSTORE
-      if (row < M && acc[m][0][0] == 12345.f) {
-#else
-      if (row < M) {
-#endif                                                //   rows 4 q + i = columns 16 nt + 4 q + i of C
+      const int up = l16 >> 3;                                       // this lane writes the pair's first (0) / second (1) column tile
+      const int r1 = t * 32 + 16 * m + (l16 & 7), r2 = r1 + 8;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          const float4 f = *reinterpret_cast<const float4*>(&css[16 * nt + 4 * q]), bb = *reinterpret_cast<const float4*>(&bss[16 * nt + 4 * q]);
-          *reinterpret_cast<float4*>(&C[(size_t)row * ldc + col0 + 16 * nt + 4 * q]) =
-              make_float4(fmaf(acc[m][nt][0], f.x, bb.x), fmaf(acc[m][nt][1], f.y, bb.y), fmaf(acc[m][nt][2], f.z, bb.z), fmaf(acc[m][nt][3], f.w, bb.w));
+      for (int nt = 0; nt < 8; nt += 2) {
+        f4v x, y;                                                    // x: the partner's second tile, y: the partner's first tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[m][nt + 1][i]), 0x128, 0xF, 0xF, false));
+          y[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[m][nt][i]), 0x128, 0xF, 0xF, false));
         }
+        const f4v v1 = up ? x : acc[m][nt], v2 = up ? acc[m][nt + 1] : y;     // rows l16 & 7 / 8 + (l16 & 7) of the row tile
+        const int cl = 16 * (nt + up) + 4 * q;
+        const float4 f = *reinterpret_cast<const float4*>(&css[cl]), bb = *reinterpret_cast<const float4*>(&bss[cl]);
+#ifdef RV_WS_NOSTORE
+        if (r1 < M && v1[0] == 12345.f)
+#else
+        if (r1 < M)
+#endif
+          *reinterpret_cast<float4*>(&C[(size_t)r1 * ldc + col0 + cl]) =
+              make_float4(fmaf(v1[0], f.x, bb.x), fmaf(v1[1], f.y, bb.y), fmaf(v1[2], f.z, bb.z), fmaf(v1[3], f.w, bb.w));
+#ifdef RV_WS_NOSTORE
+        if (r2 < M && v2[0] == 12345.f)
+#else
+        if (r2 < M)
+#endif
+          *reinterpret_cast<float4*>(&C[(size_t)r2 * ldc + col0 + cl]) =
+              make_float4(fmaf(v2[0], f.x, bb.x), fmaf(v2[1], f.y, bb.y), fmaf(v2[2], f.z, bb.z), fmaf(v2[3], f.w, bb.w));
       }
     }
   }
