@@ -1,6 +1,11 @@
 """Diagnostic: time of the fused recurrence+projection kernel with one role's math disabled (RV_DBG_ROLE)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# RV_DBG_ROLE is compiled only into the diagnostic library (`make -C ravvent-basecaller_amd/csrc diag`): the product library ignores it
+os.environ.setdefault("RAVVENT_HIP_LIB", os.path.join(ROOT, "ravvent-basecaller_amd", "csrc", "libravvent_hip_diag.so"))
+if not os.path.exists(os.environ["RAVVENT_HIP_LIB"]):
+    raise SystemExit(f"role_probe.py: {os.environ['RAVVENT_HIP_LIB']} not found -- build it with: make -C ravvent-basecaller_amd/csrc diag")
 import numpy as np, torch
 import ravvent_basecaller_amd as rv
 B, T_r, T_e, W, L = 256, 300, 30, 5, 8

@@ -53,8 +53,10 @@ void run(const float* Wm, float* out, long long* cyc, int grid) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   const double bytes = 512.0 * 1024 * passes;
-  printf("waves/CU %2d  in flight/lane %2d  workgroups %3d: %.1f B/clk/CU (s_memtime-free: %lld cycles/pass, 100 MHz counter x24)  %.1f GB/s/CU wall\n",
-         NT / 64, D, grid, bytes / ((double)c * 24.0), c / passes, bytes / (ms * 1e-3) / 1e9);
+  // c counts SHADER-clock cycles of workgroup 0 (round 3 printed bytes / (c x 24), taking the counter for a 100 MHz one: a column 24 times too
+  // small; cycles per pass and the wall rate were right -- 512 KB / 8,544 cycles = 61 B/clk, 145.6 GB/s per CU = 61 B x 2.37 GHz)
+  printf("waves/CU %2d  in flight/lane %2d  workgroups %3d: %.1f B/clk/CU (%lld shader-clock cycles per 512 KB pass)  %.1f GB/s/CU wall\n",
+         NT / 64, D, grid, bytes / (double)c, c / passes, bytes / (ms * 1e-3) / 1e9);
 }
 
 int main() {
