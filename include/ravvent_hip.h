@@ -154,8 +154,9 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       256 (two workgroups per CU) for slabs larger than the CU count),
  *          "flash_attend" (0/1, default 1 [per-step decode]: single-pass Luong attention over values only;
  *                       0 = two-pass keys-then-values dataflow of the reference),
- *          "concurrent_encoders" (0/1, default 1 [fma form, with "fused_projection" 0]: in joint mode the event encoder runs on a side stream under the
- *                       raw encoder's input-projection GEMM; results are identical),
+ *          "concurrent_encoders" (0/1, default 1: in joint mode the event encoder runs on a side stream beside the raw encoder -- on the default
+ *                       path for ONE isolated slab (a synchronous call: its matrix-pipe encoder launches use an eighth of the chip each), on the
+ *                       fma form with "fused_projection" 0 under the raw encoder's input-projection GEMM; results are identical),
  *          "fused_projection" (0/1, default 1 [fma form]: encoder layers >= 1 compute their input projection inside the
  *                       recurrence kernel, on MFMA waves of the same workgroup; 0 = separate GEMM launch + pre-projected
  *                       tensor; results agree to fp32 rounding),

@@ -556,6 +556,19 @@ int record_slab(RvContext* h, const float* xr, const float* xe, bool host_in, in
     run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 1);
     HIPCHK(h, hipEventRecord(h->ev_join[0], sev));
     HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
+  } else if (h->lwide && use_raw && use_ev && h->inflight_hint <= 1 && !ptab && h->opt_profile == 0 && h->opt_side_ev) {
+    // One isolated slab on the matrix-pipe form: every encoder launch is 2 x ceil(B / 16) workgroups (32 of the chip's 256 CUs at B = 256), so
+    // the event encoder's chain (four launches, ~0.15 ms at the C3 shape) runs on a side stream BESIDE the raw encoder's instead of in front of
+    // it: the synchronous call's latency drops by that much.  (With several slabs in flight the other slabs fill the chip: one stream per
+    // context then, no fork / join.)  The two encoders write disjoint time ranges of enc_out and of the mask and use their own xw / act / state
+    // buffers: results are identical.
+    hipStream_t sev = side_stream(h, 0);
+    HIPCHK(h, hipEventRecord(h->ev_fork, s));
+    HIPCHK(h, hipStreamWaitEvent(sev, h->ev_fork, 0));       // inputs (H2D copies on s) are in place
+    run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, sev);
+    HIPCHK(h, hipEventRecord(h->ev_join[0], sev));
+    run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s);
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
   } else {
     if (use_ev) run_encoder(h, 1, xe, 5, B, T_e, Tm, T_r, s, 0, 1 << 30, ptab);
     if (use_raw) run_encoder(h, 0, xr, 1, B, T_r, Tm, 0, s, 0, 1 << 30, ptab);
