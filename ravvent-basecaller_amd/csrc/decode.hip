@@ -1477,15 +1477,20 @@ __global__ __launch_bounds__(512) void k_dec_persist(DecState d, const float* __
         float tl = mv == -INFINITY ? 0.f : lv * __builtin_amdgcn_exp2f(mv - Mgl);
         tl += dpp<0xB1>(tl); tl += dpp<0x4E>(tl); tl += dpp<0x141>(tl);
         // all-masked chunk: 0 / 0 = NaN like the reference
-        const float rt = Mgl == -INFINITY ? __int_as_float(0x7fc00000) : 1.0f / tl;
+        const float rt = Mgl == -INFINITY ? __int_as_float(0x7fc00000) : __builtin_amdgcn_rcpf(tl);   // (v_rcp_f32: 1 ulp; the IEEE division is a dozen dependent instructions on this phase's critical path)
         // alignments -> A fragments of the context product: [k-block t / 8][row mx_row(beam) (+ 1: low part)][t % 8] f16 of alpha 2^14 (in `part`,
         // idle between the gates and the cell product at the end of the step)
         _Float16* aa = reinterpret_cast<_Float16*>(part);
+        float Mg_[NI], rr_[NI];                                // (both beams' pairs fetched before either is used: one LDS round trip, not two)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          Mg_[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * (kq + 4 * i), __float_as_int(Mgl)));
+          rr_[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * (kq + 4 * i), __float_as_int(rt)));
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int beam = kq + 4 * i;                         // its merged pair sits in lanes 8 beam .. 8 beam + 7
-          const float Mg = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * beam, __float_as_int(Mgl)));
-          const float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(32 * beam, __float_as_int(rt)));
+          const float Mg = Mg_[i], rr = rr_[i];
           const bool nanrow = rr != rr && beam < W;
           const float f = (beam >= W || mrow_[i] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mrow_[i] - Mg) * rr * 16384.f;
 #pragma unroll
