@@ -100,8 +100,14 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 
   float hl[4] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
+  // diagnostic (RV_REC_STAMPS, tools/rec_stamps.py): cycle sums of workgroup (0, 0), wave 0 over all steps: [0] top of step -> gate sums in
+  // registers, [1] -> cell update done, [2] -> LDS image and output store issued, [3] -> behind the barrier
+  const bool stamp = a.dbg_ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  long long st_sum[4] = {0, 0, 0, 0};
   auto step = [&](int s, const float4 (&xu)[4], float4 (&xl)[4]) {
     const int t = dir ? T - 1 - s : s;
+    long long st0 = 0;
+    if (stamp) st0 = __builtin_readcyclecounter();
     if (F == 0) {                                                // the inputs of step s + 2: in flight across two barriers
       const int tn = dir ? max(t - 2, 0) : min(t + 2, T - 1);
 #pragma unroll
@@ -111,17 +117,20 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
     const char* hp = hb + cur * 8192 + (q * 16 + n) * 16;
+#ifndef RV_MX_NOMFMA     // (timing ablation builds: results invalid)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const h8 bh = *reinterpret_cast<const h8*>(hp + ks * 1024), bl = *reinterpret_cast<const h8*>(hp + 4096 + ks * 1024);
+      // the four gates in turns for each part product: an MFMA accumulates onto a result that is four instructions old, not onto the one
+      // issued just before it (per accumulator the order of the additions is unchanged: identical results)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const h8 ah = __builtin_bit_cast(h8, ua[g][ks][0]), al = __builtin_bit_cast(h8, ua[g][ks][1]);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
-      }
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][0]), bl, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][1]), bh, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][0]), bh, acc[g], 0, 0, 0);
     }
+#endif
     // ---- gate pre-activations of this lane's 4 units, cell update (i, f, c~, o)
     float z[4][4];
 #pragma unroll
@@ -137,15 +146,35 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
       z[g][0] = fmaf(acc[g][0], ds.x, xin.x); z[g][1] = fmaf(acc[g][1], ds.y, xin.y);
       z[g][2] = fmaf(acc[g][2], ds.z, xin.z); z[g][3] = fmaf(acc[g][3], ds.w, xin.w);
     }
+    if (stamp) { asm volatile("" :: "v"(z[0][0]), "v"(z[3][3])); const long long tn = __builtin_readcyclecounter(); st_sum[0] += tn - st0; st0 = tn; }
     h4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#if defined(RV_MX_NOGATES)   // (timing ablation builds: results invalid)
+      const float cc = z[1][i] * c[i] + z[0][i] * z[2][i];
+      const float hh = z[3][i] * cc;
+#elif !defined(RV_MX_PLAIN_CELL)
+      // The cell update on 7 transcendentals instead of 10 (the step is bound by vector issue, and a transcendental costs four
+      // ordinary instructions): with E_x = 2^(-log2(e) z_x) for the three sigmoid gates and E_g = 2^(2 log2(e) z_g) for the candidate,
+      //   c' = sig(f) c + sig(i) tanh(g) = [c (1 + E_i)(1 + E_g) + (E_g - 1)(1 + E_f)] / [(1 + E_f)(1 + E_i)(1 + E_g)]      (3 exp, ONE rcp)
+      //   h' = sig(o) tanh(c')           = (E_c - 1) / [(1 + E_o)(1 + E_c)],  E_c = 2^(2 log2(e) c')                        (2 exp, ONE rcp)
+      // Exponents clamped to +-30 (sigmoid / tanh are saturated to f32 precision there; the triple product stays far below FLT_MAX).
+      constexpr float L2E = 1.4426950408889634f;
+      auto ex = [](float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -30.f, 30.f)); };
+      const float Ei = ex(-L2E * z[0][i]), Ef = ex(-L2E * z[1][i]), Eg = ex(2.f * L2E * z[2][i]), Eo = ex(-L2E * z[3][i]);
+      const float ab = (1.f + Ei) * (1.f + Eg), df = 1.f + Ef;
+      const float cc = fmaf(c[i], ab, (Eg - 1.f) * df) * __builtin_amdgcn_rcpf(ab * df);
+      const float Ec = ex(2.f * L2E * cc);
+      const float hh = (Ec - 1.f) * __builtin_amdgcn_rcpf((1.f + Eo) * (1.f + Ec));
+#else
       const float cc = fmaf(rv_sigmoid(z[1][i]), c[i], rv_sigmoid(z[0][i]) * rv_tanh(z[2][i]));
       const float hh = rv_sigmoid(z[3][i]) * rv_tanh(cc);
+#endif
       c[i] = cc; hl[i] = hh;
       const float sv = hh * 16384.f;
       hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]);
     }
+    if (stamp) { asm volatile("" :: "v"(hl[0]), "v"(hl[3])); const long long tn = __builtin_readcyclecounter(); st_sum[1] += tn - st0; st0 = tn; }
     {
       char* dst = hb + (cur ^ 1) * 8192 + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
       *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
@@ -153,7 +182,9 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     if (live)
       *reinterpret_cast<float4*>(a.out + ((size_t)(b0 + n) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
     cur ^= 1;
+    if (stamp) { const long long tn = __builtin_readcyclecounter(); st_sum[2] += tn - st0; st0 = tn; }
     RV_MX_BARRIER();
+    if (stamp) { const long long tn = __builtin_readcyclecounter(); st_sum[3] += tn - st0; }
   };
   // whole triples in the loop, the one or two steps that are left after it: a conditional step INSIDE the loop makes the compiler merge
   // two histories of pending loads / stores at the loop header, and it then drains the vector-memory counter there (`s_waitcnt vmcnt(0)`
@@ -168,6 +199,7 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     step(s, xc, xnn);
     if (s + 1 < T) step(s + 1, xn, xc);
   }
+  if (stamp) { for (int i = 0; i < 4; ++i) a.dbg_ts[i] = st_sum[i]; a.dbg_ts[4] = T; }
   if (live) {
     *reinterpret_cast<float4*>(a.hT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
     *reinterpret_cast<float4*>(a.cT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(c[0], c[1], c[2], c[3]);

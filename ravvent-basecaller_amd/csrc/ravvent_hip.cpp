@@ -336,8 +336,10 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
         a.mask = h->mask; a.mask_T = Tm; a.mask_t0 = t_off; a.pad = h->cfg.padding_value;   // the layer-0 kernels leave the input mask too
         a.ptab = ptab;
+        a.dbg_ts = (e == 0 && h->rec_ts_layer == 0) ? h->rec_ts : nullptr;     // (RV_REC_STAMPS=1: phase cycle sums of workgroup (0, 0))
         Scope sc(h, "lstm_rec_raw_l0", s);
         launch_lstm_rec_mx(a, 1, s);
+        a.dbg_ts = nullptr;
         continue;
       }
       if (l == 0) {
@@ -350,8 +352,10 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
                                  h->d_bx2 + (size_t)(e * (depth - 1) + (l - 1)) * 2 * RV_G, h->xw[e], 2 * RV_G, s);
       }
       a.x = h->xw[e];
+      a.dbg_ts = (e == 0 && l == 1 && h->rec_ts_layer == 1) ? h->rec_ts : nullptr;    // (RV_REC_STAMPS=2)
       Scope sc(h, l == 0 ? "lstm_rec_event_l0" : (e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p"), s);
       launch_lstm_rec_mx(a, 0, s);
+      a.dbg_ts = nullptr;
       continue;
     }
     if (l == 0) {

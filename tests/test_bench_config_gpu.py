@@ -169,8 +169,9 @@ def test_stress_case_88_score_difference_is_explained(rv, oracle):
     through the fp64 oracle: the row's decode passes through a near-tie at the beam cut (a different fifth beam changes the later,
     un-back-traced top-1 scores: SURVEY.md A.5), or this test is red."""
     n_rows, n_greedy = _sweep_case(rv, oracle, "joint", 2, 1, 169, 18, 29, 4, 29, "luong", 425, -0.3332263726534489, 88, "stress seed 123 case 88")
+    # (On the round-3 kernels, and on round 4's until the encoder's cell update changed its rounding, one row differed here -- tokens equal,
+    #  scores 9.2e-4 apart -- and the fp64 re-decode showed the near-tie; a later rounding change can make the two forms agree outright.)
     print(f"case 88: {n_rows} beam rows and {n_greedy} greedy rows differed between forms, all explained by the fp64 oracle")
-    assert n_rows >= 1          # the difference the log shows is still there to be explained (fc vs the default form)
 
 
 @pytest.mark.parametrize("seed", [123, 7])
