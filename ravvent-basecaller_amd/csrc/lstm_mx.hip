@@ -102,7 +102,11 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
   int cur = 0;
   // diagnostic (RV_REC_STAMPS, tools/rec_stamps.py): cycle sums of workgroup (0, 0), wave 0 over all steps: [0] top of step -> gate sums in
   // registers, [1] -> cell update done, [2] -> LDS image and output store issued, [3] -> behind the barrier
+#ifdef RV_MX_STAMPS      // diagnostic builds only (make mxvar V=1 MXFLAGS=-DRV_MX_STAMPS; RAVVENT_HIP_LIB=...libravvent_hip_m1.so): four scalar branches per step otherwise
   const bool stamp = a.dbg_ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#else
+  constexpr bool stamp = false;
+#endif
   long long st_sum[4] = {0, 0, 0, 0};
   auto step = [&](int s, const float4 (&xu)[4], float4 (&xl)[4]) {
     const int t = dir ? T - 1 - s : s;
@@ -117,7 +121,6 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
     const char* hp = hb + cur * 8192 + (q * 16 + n) * 16;
-#ifndef RV_MX_NOMFMA     // (timing ablation builds: results invalid)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const h8 bh = *reinterpret_cast<const h8*>(hp + ks * 1024), bl = *reinterpret_cast<const h8*>(hp + 4096 + ks * 1024);
@@ -130,7 +133,6 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][0]), bh, acc[g], 0, 0, 0);
     }
-#endif
     // ---- gate pre-activations of this lane's 4 units, cell update (i, f, c~, o)
     float z[4][4];
 #pragma unroll
@@ -150,26 +152,13 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
     h4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#if defined(RV_MX_NOGATES)   // (timing ablation builds: results invalid)
-      const float cc = z[1][i] * c[i] + z[0][i] * z[2][i];
-      const float hh = z[3][i] * cc;
-#elif !defined(RV_MX_PLAIN_CELL)
-      // The cell update on 7 transcendentals instead of 10 (the step is bound by vector issue, and a transcendental costs four
-      // ordinary instructions): with E_x = 2^(-log2(e) z_x) for the three sigmoid gates and E_g = 2^(2 log2(e) z_g) for the candidate,
-      //   c' = sig(f) c + sig(i) tanh(g) = [c (1 + E_i)(1 + E_g) + (E_g - 1)(1 + E_f)] / [(1 + E_f)(1 + E_i)(1 + E_g)]      (3 exp, ONE rcp)
-      //   h' = sig(o) tanh(c')           = (E_c - 1) / [(1 + E_o)(1 + E_c)],  E_c = 2^(2 log2(e) c')                        (2 exp, ONE rcp)
-      // Exponents clamped to +-30 (sigmoid / tanh are saturated to f32 precision there; the triple product stays far below FLT_MAX).
-      constexpr float L2E = 1.4426950408889634f;
-      auto ex = [](float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -30.f, 30.f)); };
-      const float Ei = ex(-L2E * z[0][i]), Ef = ex(-L2E * z[1][i]), Eg = ex(2.f * L2E * z[2][i]), Eo = ex(-L2E * z[3][i]);
-      const float ab = (1.f + Ei) * (1.f + Eg), df = 1.f + Ef;
-      const float cc = fmaf(c[i], ab, (Eg - 1.f) * df) * __builtin_amdgcn_rcpf(ab * df);
-      const float Ec = ex(2.f * L2E * cc);
-      const float hh = (Ec - 1.f) * __builtin_amdgcn_rcpf((1.f + Eo) * (1.f + Ec));
-#else
+      // (Round 4 tried this update on 7 transcendentals instead of 10 -- c' and h' each as ONE reciprocal of a product of (1 + 2^x) terms --
+      //  parity-green and no faster: 0.394 / 0.424 ms per C3 layer either way.  The step is bound by the SIMD's issue with both of its waves
+      //  in the same phase -- tools/mx_stamps.py: 1.24 k cycles of MFMA phase + 1.0 k of cell update + 0.26 k + 0.7 k at the barrier -- and a
+      //  two-group form that interleaves one group's MFMAs with the other's cell update inside every wave did not overlap them either
+      //  (DESIGN.md section 7).)
       const float cc = fmaf(rv_sigmoid(z[1][i]), c[i], rv_sigmoid(z[0][i]) * rv_tanh(z[2][i]));
       const float hh = rv_sigmoid(z[3][i]) * rv_tanh(cc);
-#endif
       c[i] = cc; hl[i] = hh;
       const float sv = hh * 16384.f;
       hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]);

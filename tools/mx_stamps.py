@@ -1,5 +1,7 @@
 """Diagnostic: where a step of the matrix-pipe recurrence (k_lstm_rec_mx) goes -- cycle sums of workgroup (0, 0), wave 0 over all steps.
-RV_REC_STAMPS=1: raw layer 0; =2: raw layer 1.  usage: RV_REC_STAMPS=1 python tools/mx_stamps.py"""
+RV_REC_STAMPS=1: raw layer 0; =2: raw layer 1.  Needs the stamps build of the kernel:
+  make -C ravvent-basecaller_amd/csrc mxvar V=1 MXFLAGS=-DRV_MX_STAMPS
+  RAVVENT_HIP_LIB=$PWD/ravvent-basecaller_amd/csrc/libravvent_hip_m1.so RV_REC_STAMPS=1 python tools/mx_stamps.py"""
 import os, sys
 os.environ.setdefault("RV_REC_STAMPS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
