@@ -470,7 +470,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   }
 
   h->lwide = wide_recurrence(h, B, T_r) ? 1 : 0;
-  if ((!h->opt_fuse && c.enc_depth > 1) || h->lwide) {   // pre-projected tensors [max_batch, T_max, 2, 512] (unfused path, matrix-pipe recurrence), allocated on first use
+  if ((!h->opt_fuse && c.enc_depth > 1) || h->lwide) {   // pre-projected tensors [max_batch, T_max, 2, 512]: allocated with the context (alloc_slab_buffers); this is a safety net
     if (use_raw && c.enc_depth > 1 && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
     if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
   }
@@ -825,7 +825,12 @@ int alloc_slab_buffers(RvContext* h) {
     if (use_raw) TRY(dalloc(h, &h->act[0][p], B * Tr * RV_E));
     if (use_ev) TRY(dalloc(h, &h->act[1][p], B * Te * RV_E));
   }
-  // (the pre-projected tensors xw of the unfused path -- 4 KB per chunk-timestep -- are allocated on first use: run_encoder)
+  // The pre-projected tensors xw [max_batch, T_max, 2, 512] (4 KB per chunk-timestep) of the matrix-pipe recurrence (the default) and of the
+  // unfused packed-FMA path: allocated HERE, with the context -- not on a context's first call.  (Round 4 found the first-use hipMalloc of a
+  // fresh context inside bench.py's timed region: the driver's 5 warm-up steps touch 5 of the 10 contexts, the other five allocated 2 x ~300 MB
+  // each while the GPU drained -- 1.5 to 10 ms of host stall per context, which rounds 3 and 4 had read as the pipeline's fill time.)
+  if (use_raw && c.enc_depth > 1) TRY(dalloc(h, &h->xw[0], B * Tr * 2 * RV_G));
+  if (use_ev) TRY(dalloc(h, &h->xw[1], B * Te * 2 * RV_G));
   for (int e = 0; e < 2; ++e)
     for (int st = 0; st < 2; ++st)
       for (int k = 0; k < 4; ++k) TRY(dalloc(h, &h->st[e][st][k], B * RV_U));
