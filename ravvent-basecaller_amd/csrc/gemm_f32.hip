@@ -371,6 +371,9 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const float4 x0 = ar[ks % RING][m][0], x1 = ar[ks % RING][m][1];
+#ifdef RV_WS_PRESPLIT   // (diagnostic builds, results invalid: what the k-loop costs when A arrives as f16 parts)
+        __builtin_memcpy(&ah[m], &x0, 16); __builtin_memcpy(&al[m], &x1, 16);
+#else
         const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
           ah[m][j] = (_Float16)sv;
           al[m][j] = (_Float16)(sv - (float)ah[m][j]);
         }
+#endif
       }
 #ifndef RV_WS_NOALOAD   // (diagnostic builds: results invalid)
       if (ks + RING < 8) RV_WS_LOAD(t, ks + RING, ks % RING); else RV_WS_LOAD(tn, ks + RING - 8, ks % RING);     // stream position + RING, into the slot just consumed
@@ -388,6 +392,13 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
       // wait out the full pipeline latency: the first form of this loop, one column tile per group, ran at a third of the MFMA rate).
       // Operands swapped: a tile comes out TRANSPOSED (rows = 16 columns of C, columns = the 16 rows of the row tile), so a lane ends
       // up with 4 consecutive columns of one row of C: a 16-byte store instead of four 4-byte ones.
+#ifdef RV_WS_NOMFMA   // (diagnostic builds: results invalid -- the memory side alone)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m][ks][j & 3] += (float)ah[m][j] + (float)al[m][j];
+      (void)bs;
+#else
 #pragma unroll
       for (int np = 0; np < 8; np += 2) {
         const h8 bh0 = *reinterpret_cast<const h8*>(bs + (2 * np) * 1024), bl0 = *reinterpret_cast<const h8*>(bs + (2 * np + 1) * 1024);
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
         acc[1][np + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh1, ah[1], acc[1][np + 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
     // Epilogue.  C/D map of the transposed tile: lane (l16 = row of C, q) holds columns 16 nt + 4 q + 0..3 -- a store instruction of one
     // column tile would write 64 bytes to each of 16 rows (half cache lines, rows 4 KB apart).  Two column tiles are paired instead:
@@ -415,7 +427,18 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
     // (Tried with it and dropped: whole-line A loads by the same exchange, the weight image in the matching k order -- parity-identical, but
     //  52 B of scratch at twelve waves, 0.165 ms; eight waves 0.154-0.163.  Ablations of this kernel, tools/gemm_ab.py: without the stores
     //  0.105 ms, without the A loads 0.097, without either 0.082, and with a quarter of the MFMAs and no LDS reads still 0.145: the launch is
-    //  bound by its memory side -- 394 MB at 2.7-2.9 TB/s where a plain fill of the 315 MB output runs at 6.7 TB/s.)
+    //  bound by its memory side -- 394 MB at 2.7-2.9 TB/s where a plain fill of the 315 MB output runs at 6.7 TB/s.
+    //  Second pass of ablations, -DRV_WS_NOMFMA builds = the memory side alone: stores alone 0.056 ms, A loads alone 0.108, both 0.184; MFMAs
+    //  + LDS reads alone 0.082.  Timed and dropped, each with the stores' `nt` hint: the output as [tile][column half][32][128] so that a wave's
+    //  tile leaves as one contiguous 16 KB: 0.122 against 0.121; A in a blocked order so that every load instruction reads one contiguous KB
+    //  (results invalid, timing only): loads alone 0.072, the whole kernel 0.122 -- the access pattern of neither stream is the bound; every
+    //  workgroup touching 1 / 8 of the 64-byte sectors of the tile its waves take two tiles later, so that the stream positions come from L2:
+    //  0.147; A arriving as f16 parts, no conversion in the loop (-DRV_WS_PRESPLIT, timing only): 0.115; MFMAs + LDS reads alone then 0.0815.)
+    // Nontemporal stores (round 4): the 315 MB of xw are read again only after the whole launch, by another kernel -- written with the
+    // `nt` hint they do not push the A rows that the other column blocks of the row group still need out of L2: 0.139 -> 0.121 ms.
+    // (The same hint on k_gemm_mem_split3's half-line stores: 0.051 -> 0.057 ms; not there.)
+#define RV_WS_ST(p_, v_) do { const float4 v__ = (v_); __builtin_nontemporal_store(v__.x, (p_)); __builtin_nontemporal_store(v__.y, (p_) + 1); \
+    __builtin_nontemporal_store(v__.z, (p_) + 2); __builtin_nontemporal_store(v__.w, (p_) + 3); } while (0)      /* one global_store_dwordx4 ... nt */
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int up = l16 >> 3;                                       // this lane writes the pair's first (0) / second (1) column tile
@@ -436,19 +459,20 @@ __global__ __launch_bounds__(RV_WS_THREADS) void k_gemm_ws(const float* __restri
 #else
         if (r1 < M)
 #endif
-          *reinterpret_cast<float4*>(&C[(size_t)r1 * ldc + col0 + cl]) =
-              make_float4(fmaf(v1[0], f.x, bb.x), fmaf(v1[1], f.y, bb.y), fmaf(v1[2], f.z, bb.z), fmaf(v1[3], f.w, bb.w));
+          RV_WS_ST(&C[(size_t)r1 * ldc + col0 + cl],
+              make_float4(fmaf(v1[0], f.x, bb.x), fmaf(v1[1], f.y, bb.y), fmaf(v1[2], f.z, bb.z), fmaf(v1[3], f.w, bb.w)));
 #ifdef RV_WS_NOSTORE
         if (r2 < M && v2[0] == 12345.f)
 #else
         if (r2 < M)
 #endif
-          *reinterpret_cast<float4*>(&C[(size_t)r2 * ldc + col0 + cl]) =
-              make_float4(fmaf(v2[0], f.x, bb.x), fmaf(v2[1], f.y, bb.y), fmaf(v2[2], f.z, bb.z), fmaf(v2[3], f.w, bb.w));
+          RV_WS_ST(&C[(size_t)r2 * ldc + col0 + cl],
+              make_float4(fmaf(v2[0], f.x, bb.x), fmaf(v2[1], f.y, bb.y), fmaf(v2[2], f.z, bb.z), fmaf(v2[3], f.w, bb.w)));
       }
     }
   }
 #undef RV_WS_LOAD
+#undef RV_WS_ST
 }
 constexpr int GEMM_WS_LDS = 131072 + 1024;
 
