@@ -423,12 +423,14 @@ def main():
     x0 = (d_raw[lo:lo + B], d_ev[lo:lo + B])       # this rank's first slab: what the untimed per-kernel passes run on
     Bk = int(x0[0].shape[0])
     chunk_steps, prof_iso, sync_ms, sync_auto_ms, verified = None, {}, None, None, None
-    # which recurrence form the timed region ran (auto: the matrix form when more than 256 chunks are in flight together)
-    wide_used = {"mx": True, "fma": False, "auto": Bk * max(depth, 1) > 256}[args.recurrence]
+    # which recurrence form the timed region ran (auto: the library's per-call rule on the chunks in flight)
+    n_fl = Bk * max(depth, 1)
+    form_used = {"mx": 1, "fma": 0, "auto": 0 if n_fl < 160 else (2 if n_fl <= 512 else 1)}[args.recurrence]     # (the library's rule for -1)
+    wide_used = form_used != 0
     if rank == 0:
         # every launch ALONE on the chip, in a short untimed pass of synchronous calls with the timed region's kernel selection
         # (local decode only: no collective here)
-        bc.set_option("wide_recurrence", 1 if wide_used else 0)
+        bc.set_option("wide_recurrence", form_used)
         bc.set_option("profile", 1)
         bc.reset_profile()
         for _ in range(10):
@@ -519,7 +521,7 @@ def main():
             while r < bt and r < 8:
                 r <<= 1
             return r
-        rec_wgs = 2 * -(-Bk // 16) if wide_used else 2 * -(-Bk // rows_per_block(Bk))
+        rec_wgs = 2 * -(-Bk // (8 if form_used == 2 else 16)) if wide_used else 2 * -(-Bk // rows_per_block(Bk))
         for k in per_slab:
             if k.startswith("lstm_rec"):
                 wgs[k] = rec_wgs
@@ -627,7 +629,7 @@ def main():
                        "pipelining": (f"the {args.steps} timed steps stream through the asynchronous calls (rv_beam_search_submit_dev / collect_dev), "
                                       f"{depth} slabs in flight, every step collected inside the timed region; results byte-identical to the synchronous call"
                                       if depth else "synchronous calls, one slab at a time"),
-                       "recurrence": ("matrix pipe, 16 chunks per workgroup (k_lstm_rec_mx + split-f16 projection GEMM)" if wide_used
+                       "recurrence": (f"matrix pipe, {8 if form_used == 2 else 16} chunks per workgroup (k_lstm_rec_mx + split-f16 projection GEMM)" if wide_used
                                       else "packed fp32 FMAs (k_lstm_rec_tw / k_lstm_rec_proj)"),
                        "parallelism": f"chunk-shard x{world}" + ((" + 1 RCCL all-gather/step (dist.sharded_beam_search_stream)" if (args.gather_per_step or not depth) else
                                                                        " + ONE RCCL all-gather at the end of the steps (dist.sharded_beam_search_many)") if dist_path else "")},
@@ -660,8 +662,9 @@ def main():
                                   "note": "rv_beam_search_dev, one slab at a time, the SAME kernels as the headline (recurrence form "
                                           f"'{args.recurrence}'); untimed extra: 20 calls after the timed region"}
             out["synchronous_auto"] = {"ms_per_step": round(sync_auto_ms, 4), "chunks_per_s": round(Bk / sync_auto_ms * 1e3, 1),
-                                       "note": "the same with wide_recurrence = -1 (form chosen per call: the packed-FMA recurrences for one isolated "
-                                               "slab of <= 256 chunks -- other kernels than the headline's; results agree to f32 rounding)"}
+                                       "note": "the same with wide_recurrence = -1 (form chosen per call: for one isolated slab of 160-512 chunks the matrix-pipe "
+                                               "recurrence with EIGHT chunks per workgroup, the latency form -- other kernels than the headline's; results "
+                                               "agree to f32 rounding)"}
     bc.close()
     if rank == 0:
         if world == 1 and not args.no_extras:      # sub-lines outside the timed region (own handles)

@@ -117,8 +117,8 @@ int rv_beam_search_calls(rv_handle h, const float* raw, const float* event, int3
  * ravvent_performance_evaluator.py:51-55).  The handle owns "async_depth" slab contexts (own stream and buffers, one set of
  * weights); rv_beam_search_submit* queues a slab's whole path on an idle context and returns a ticket without waiting for the
  * GPU, rv_beam_search_collect* waits for that slab and hands out its results, which are byte-identical to the synchronous
- * call's (with option "wide_recurrence" at 1, the default, or 0; at -1 the recurrence form is chosen per call from the slabs in flight,
- * and the two forms agree to f32 rounding only).  Up to async_depth slabs are in flight: slab k+1's encoders run beside the tail of slab k's decode (chunks leave the
+ * call's (with option "wide_recurrence" at 1, the default, 2 or 0; at -1 the recurrence form is chosen per call from the slabs in flight,
+ * and the forms agree to f32 rounding only).  Up to async_depth slabs are in flight: slab k+1's encoders run beside the tail of slab k's decode (chunks leave the
  * decode as their beams finish), and with several slabs in flight the encoder recurrences switch to 16 chunks per workgroup on
  * the matrix pipe (option "wide_recurrence").  Tickets may be collected in any order; submit fails with RV_ESTATE when every
  * context holds an uncollected call.  Same single-thread rule as the rest of the handle.
@@ -167,15 +167,17 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "tail_wave"  (0/1, default 1 [fma form]: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
  *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
  *                       agree to fp32 rounding),
- *          "wide_recurrence" (1/0/-1, default 1: the encoder recurrences as ONE split-f16 MFMA product per step for 16 chunks of a
+ *          "wide_recurrence" (1/2/0/-1, default 1: the encoder recurrences as ONE split-f16 MFMA product per step for 16 chunks of a
  *                       direction per workgroup (raw layer 0 with its input projection in the lane, the other layers on inputs
- *                       pre-projected by an elementwise kernel / a split-f16 GEMM); 0 = packed fp32 FMAs on 1-8 chunks per
- *                       workgroup with the projection fused in ("fused_projection", "split_projection", "tail_wave" configure that
- *                       form).  The matrix form costs per workgroup, the FMA form per chunk: the matrix form wins as soon as more
- *                       than 256 chunks are in flight (one large slab, or several through the asynchronous calls), the FMA form has
- *                       the lower latency for ONE isolated slab of <= 256 chunks (C3 shape: 1.40 vs 1.86 ms).  -1 = choose per call
- *                       by that rule -- fastest, but the two forms agree to f32 rounding only, so results then depend on the slab
- *                       size; with 1 or 0 a chunk's result never depends on the slab or shard it travels in),
+ *                       pre-projected by an elementwise kernel / a split-f16 GEMM); 2 = the same with EIGHT chunks per workgroup,
+ *                       both f16 parts of a chunk's state in the product's columns: a shorter step (0.29 vs 0.40 ms per C3 layer)
+ *                       on twice the workgroups -- the latency form; 0 = packed fp32 FMAs on 1-8 chunks per workgroup with the
+ *                       projection fused in ("fused_projection", "split_projection", "tail_wave" configure that form).  The
+ *                       matrix forms cost per workgroup, the FMA form per chunk.  -1 = choose per call from the chunks in flight
+ *                       (this call's slab x the calls in flight): FMA below 160, form 2 up to 512, form 1 above -- fastest (one
+ *                       isolated C3 slab: 1.13 ms against 1.34 with form 1), but the forms agree to f32 rounding only, so results
+ *                       then depend on the slab size and on what else is in flight; with 1, 2 or 0 a chunk's result never depends on
+ *                       the slab or shard it travels in),
  *          "async_depth" (1..16, default 2: contexts the rv_beam_search_submit* calls rotate through; returns the warning RV_WQUEUES -- the
  *                       option is set -- when the value exceeds GPU_MAX_HW_QUEUES as found in the environment, see "Hardware queues" above),
  *          "slab_graph" (0/1, default 0: a call on the default path -- matrix-pipe recurrences, persistent decode, no profiling, no taps --

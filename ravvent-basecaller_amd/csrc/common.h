@@ -52,7 +52,7 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
 // [B,T,1], a.W / a.bias per direction); F == 0: a.x = pre-projected inputs xw [B,T,2,512] (bias folded).  Needs a.Ua.
 #define RV_MX_ROWS 16
 #define RV_UA_SLOT ((size_t)2 * RV_U * RV_G + 2 * RV_G)
-void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s);
+void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s, bool rows8 = false);   // rows8: eight chunks per workgroup (latency form)
 bool lstm_rec_mx_window_fits(int T);
 hipError_t configure_mx_kernels();
 // xw [rows,2,512] = x [rows,F] . W_dir [F,512] + b_dir for a layer-0 encoder with F = 5 (or 1) input features, both directions

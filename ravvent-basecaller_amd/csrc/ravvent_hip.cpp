@@ -88,6 +88,7 @@ struct RvContext {
   int opt_wide = 1;                         // matrix-pipe recurrence, 16 chunks per workgroup: 1 on (default: every call runs the same kernels whatever its slab
                                             // size, so results do not depend on how a read is cut into slabs / shards), 0 packed-FMA kernels, -1 per-call choice
   int lwide = 0;
+  int lrows8 = 0;                           // this call's matrix-pipe recurrences take eight chunks per workgroup (the latency form of lstm_mx.hip)
   int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
   int dbg_role = 0;                         // timing probe (RV_DBG_ROLE): 1 = no projection math, 2 = no recurrence math
@@ -300,10 +301,19 @@ bool wide_recurrence(const RvContext* h, int B, int T_r) {
   if (h->opt_wide == 0 || !h->opt_fuse) return false;
   if (h->cfg.mode != RV_MODE_EVENT && !lstm_rec_mx_window_fits(T_r)) return false;
   if (h->opt_wide > 0) return true;
-  // the packed-FMA kernels cost per row, the matrix form per workgroup: it pays once the slabs in flight together give the
-  // FMA kernels 4 rows per workgroup (one slab of > 256 chunks, or two 256-chunk slabs in flight through the asynchronous calls;
-  // measured at T = 300 + 30: 512 chunks 185 k -> 199 k chunks/s, two slabs of 256 in flight 200 k -> 218 k)
-  return pick_rows_per_block(B * std::max(h->inflight_hint, 1)) >= 4;
+  // Per-call choice (-1).  The packed-FMA kernels cost per chunk, the matrix forms per workgroup.  Synchronous calls at T = 300 + 30
+  // (tools/rows8_ab.py, k chunks/s; FMA / matrix pipe with 8 / with 16 chunks per workgroup): 64 chunks 75 / 64 / 53; 128: 146 / 124 / 102;
+  // 192: 159 / 181 / 150; 256: 203 / 224 / 189; 512: 208 / 298 / 266; 1,024: 212 / 342 / 341 -- FMA below 160 chunks in flight, the
+  // eight-chunk form up to 512, sixteen above (less CU-time per chunk: what a stream of slabs wants).
+  return (long long)B * std::max(h->inflight_hint, 1) >= 160;
+}
+
+// ... and with eight chunks per workgroup (two MFMAs per tile and k-step, half the cell update per lane: a shorter step on twice the
+// workgroups)?  wide_recurrence = 2 always; = -1 (per-call choice) when the slabs in flight leave the chip room for it.
+bool rows8_wanted(const RvContext* h, int B) {
+  if (h->opt_wide == 2) return true;
+  const long long n = (long long)B * std::max(h->inflight_hint, 1);
+  return h->opt_wide < 0 && n >= 160 && n <= 512;
 }
 
 void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int Tm, int t_off, hipStream_t s,
@@ -338,7 +348,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
         a.ptab = ptab;
         a.dbg_ts = (e == 0 && h->rec_ts_layer == 0) ? h->rec_ts : nullptr;     // (RV_REC_STAMPS=1: phase cycle sums of workgroup (0, 0))
         Scope sc(h, "lstm_rec_raw_l0", s);
-        launch_lstm_rec_mx(a, 1, s);
+        launch_lstm_rec_mx(a, 1, s, h->lrows8 != 0);
         a.dbg_ts = nullptr;
         continue;
       }
@@ -354,7 +364,7 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       a.x = h->xw[e];
       a.dbg_ts = (e == 0 && l == 1 && h->rec_ts_layer == 1) ? h->rec_ts : nullptr;    // (RV_REC_STAMPS=2)
       Scope sc(h, l == 0 ? "lstm_rec_event_l0" : (e == 0 ? "lstm_rec_raw_l1p" : "lstm_rec_event_l1p"), s);
-      launch_lstm_rec_mx(a, 0, s);
+      launch_lstm_rec_mx(a, 0, s, h->lrows8 != 0);
       a.dbg_ts = nullptr;
       continue;
     }
@@ -470,6 +480,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
   }
 
   h->lwide = wide_recurrence(h, B, T_r) ? 1 : 0;
+  h->lrows8 = h->lwide && rows8_wanted(h, B) ? 1 : 0;
   if ((!h->opt_fuse && c.enc_depth > 1) || h->lwide) {   // pre-projected tensors [max_batch, T_max, 2, 512]: allocated with the context (alloc_slab_buffers); this is a safety net
     if (use_raw && c.enc_depth > 1 && !h->xw[0]) { const int rc = dalloc(h, &h->xw[0], (size_t)c.max_batch * c.max_raw_len * 2 * RV_G); if (rc != RV_OK) return rc; }
     if (use_ev && !h->xw[1]) { const int rc = dalloc(h, &h->xw[1], (size_t)c.max_batch * c.max_event_len * 2 * RV_G); if (rc != RV_OK) return rc; }
@@ -487,7 +498,7 @@ int enqueue(RvContext* h, const float* raw, const float* ev, bool dev_in, int B,
     h->slab_graphs.clear();
     h->graph_gen = root->opt_gen;
   }
-  const bool graphable = root->opt_slab_graph && h->lwide && persist_wanted(h, greedy, W, T_r + T_e) && h->opt_profile == 0 && !h->opt_taps &&
+  const bool graphable = root->opt_slab_graph && h->lwide && !h->lrows8 && persist_wanted(h, greedy, W, T_r + T_e) && h->opt_profile == 0 && !h->opt_taps &&
                          !h->opt_ptaps && !h->rec_ts && !h->dec_st.dbg_ts && h->d_ptab;
   if (!graphable) return record_slab(h, xr, xe, !dev_in, B, T_r, T_e, W, L, greedy, tk, o2, dev_out, lut, nullptr);
   h->pin_ptab[RV_PTAB_RAW] = xr; h->pin_ptab[RV_PTAB_EVENT] = xe; h->pin_ptab[RV_PTAB_TOKENS] = tk; h->pin_ptab[RV_PTAB_OUT2] = o2;
@@ -1453,7 +1464,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
-  else if (!strcmp(key, "wide_recurrence")) h->opt_wide = value < 0 ? -1 : (value != 0);
+  else if (!strcmp(key, "wide_recurrence")) h->opt_wide = value < 0 ? -1 : (value == 2 ? 2 : (value != 0));
   else if (!strcmp(key, "async_depth")) {
     if (value < 1 || value > RV_MAX_ASYNC) return fail(h, RV_EINVAL, "async_depth must be 1..%d", RV_MAX_ASYNC);
     h->opt_async_depth = value;

@@ -447,7 +447,7 @@ def test_matrix_pipe_recurrence_matches_fma_path_and_oracle(rv, oracle, mode, B,
     x = _inputs(rv, mode, raw, ev)
     out, enc = {}, {}
     bc.set_option("profile", 1)
-    for wide in (1, 0):
+    for wide in (1, 2, 0):                                  # 16 chunks per workgroup; 8 (the latency form: both f16 parts of h in the product's columns); packed FMA
         bc.set_option("wide_recurrence", wide)
         bc.reset_profile()
         tok, sc = bc.beam_search_prediction(x, 5, 12)
@@ -458,12 +458,13 @@ def test_matrix_pipe_recurrence_matches_fma_path_and_oracle(rv, oracle, mode, B,
     nb = min(B, 24)
     e64, _ = oracle.encode_input(w, raw[:nb] if mode != "event" else None, ev[:nb] if mode != "raw" else None, mode, 0.0, np.float64)
     err = {k: float(np.abs(enc[k][:nb] - e64).max()) for k in enc}
-    print(f"{mode} B={B} depth={depth}: max |enc_output - fp64| matrix pipe {err[1]:.2e}, packed FMA {err[0]:.2e}")
-    assert err[1] < TOL and err[1] <= 2.0 * err[0] + 1e-6, err
-    assert np.abs(enc[1] - enc[0]).max() < TOL
-    assert out[1][0].shape == out[0][0].shape and np.abs(out[1][1] - out[0][1]).max() < TOL
-    same = (out[1][0] == out[0][0]).all(axis=1)
-    assert same.mean() >= 0.98, same.mean()                 # (a near-tie may flip between two fp32 paths; test_full_size explains such rows)
+    print(f"{mode} B={B} depth={depth}: max |enc_output - fp64| matrix pipe {err[1]:.2e}, its 8-chunk form {err[2]:.2e}, packed FMA {err[0]:.2e}")
+    for k in (1, 2):
+        assert err[k] < TOL and err[k] <= 2.0 * err[0] + 1e-6, err
+        assert np.abs(enc[k] - enc[0]).max() < TOL
+        assert out[k][0].shape == out[0][0].shape and np.abs(out[k][1] - out[0][1]).max() < TOL
+        same = (out[k][0] == out[0][0]).all(axis=1)
+        assert same.mean() >= 0.98, same.mean()             # (a near-tie may flip between two fp32 paths; test_full_size explains such rows)
     bc.close()
 
 
@@ -804,7 +805,7 @@ def test_fused_postprocessing_matches_host_form(rv):
     bc.close()
 
 
-@pytest.mark.parametrize("depth,wide", [(2, -1), (4, -1), (3, 1), (8, 0)])
+@pytest.mark.parametrize("depth,wide", [(2, -1), (4, -1), (3, 1), (4, 2), (8, 0)])
 def test_asynchronous_calls_match_synchronous(rv, depth, wide):
     """rv_beam_search_submit* / collect*: several slabs in flight on the handle's contexts (own streams and buffers, shared
     weights) give byte-identical results to the synchronous calls -- host inputs, device inputs, the fused post-processing, tickets
@@ -819,7 +820,10 @@ def test_asynchronous_calls_match_synchronous(rv, depth, wide):
     ref = [(t.numpy().copy(), s.numpy().copy()) for t, s in ref]
     ref_calls = [bc.beam_search_call_arrays(x, 5, 24) for x in slabs]
     bc.set_async_depth(depth)
-    same = lambda got, want: got[0].shape == want[0].shape and (np.asarray(got[0].cpu()) == want[0]).all() and np.array_equal(np.asarray(got[1].cpu()), want[1])
+    if wide >= 0:
+        same = lambda got, want: got[0].shape == want[0].shape and (np.asarray(got[0].cpu()) == want[0]).all() and np.array_equal(np.asarray(got[1].cpu()), want[1])
+    else:     # per-call choice of the recurrence form from the chunks in flight (40 alone: packed FMA; 4 x 40: matrix pipe): f32 rounding apart
+        same = lambda got, want: got[0].shape == want[0].shape and (np.asarray(got[0].cpu()) == want[0]).all() and np.abs(np.asarray(got[1].cpu()) - want[1]).max() < 1e-5
     # host inputs, in order
     outs = list(bc.beam_search_stream(slabs, 5, 24))
     assert len(outs) == len(slabs) and all(same(o, r) for o, r in zip(outs, ref))
@@ -838,7 +842,7 @@ def test_asynchronous_calls_match_synchronous(rv, depth, wide):
     assert all(same(o, r) for o, r in zip(outs, ref))
     # fused post-processing
     for got, want in zip(bc.beam_search_stream(slabs, 5, 24, calls=True), ref_calls):
-        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+        assert all(np.array_equal(g, w) if wide >= 0 or g.dtype.kind != "f" else np.abs(g - w).max() < 1e-5 for g, w in zip(got, want))
     # the synchronous call still works between asynchronous ones, and an empty slab passes through
     t = bc.submit_beam_search(slabs[0], 5, 24)
     t_empty = bc.submit_beam_search((slabs[0][0][:0], slabs[0][1][:0]), 5, 24) if depth > 2 else None
