@@ -513,9 +513,15 @@ def main():
         # workgroups per launch -> the share of the chip a launch can use, and from it the kernel's CU-time per slab: with several
         # slabs in flight that, not the launch duration, is what a kernel costs the whole job
         Tm = T_r + T_e
+        def ws_wgs(M):                  # launch_gemm_split_blocks' grid for the weight-stationary form (8 half column blocks, 12 waves)
+            k, ntile = 4, -(-M // 32)
+            while k > 1 and 8 * (k - 1) * 12 >= ntile:
+                k -= 1
+            return 8 * k * 8
         wgs = {"dec_persist": Bk, "dec_finalize": 0, "input_mask": 0,
-               "gemm_memory": min(256, -(-(Bk * Tm) // 128)), "gemm_inproj_raw": min(256, -(-(Bk * T_r) // 128)),
-               "gemm_inproj_event": min(256, -(-(Bk * T_e) // 128)), "inproj_event_l0": 256}
+               "gemm_memory": min(256, -(-(Bk * Tm) // 128)),
+               "gemm_inproj_raw": ws_wgs(Bk * T_r) if wide_used else min(256, -(-(Bk * T_r) // 128)),
+               "gemm_inproj_event": ws_wgs(Bk * T_e) if wide_used else min(256, -(-(Bk * T_e) // 128)), "inproj_event_l0": 256}
         def rows_per_block(b):          # the library's pick_rows_per_block
             bt, r = (2 * b + 255) // 256, 1
             while r < bt and r < 8:
