@@ -167,6 +167,10 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *          "tail_wave"  (0/1, default 1 [fma form]: encoder layer 0 with two or more chunks per workgroup leaves its cell update to a
  *                       ninth wave and runs its rows as two groups half a step apart; 0 = every wave does its own; results
  *                       agree to fp32 rounding),
+ *          "lane_projection" (0/1, default 1: with the matrix-pipe recurrence the EVENT encoder's layer 0 takes its five-feature input
+ *                       projection in the lane, from LDS windows of its chunks' events, as the raw encoder's layer 0 always does with its
+ *                       one feature: no projection launch, no pre-projected tensor; 0 = k_inproj_small + pre-projected inputs.
+ *                       Identical results: the same fused multiply-adds in the same order),
  *          "wide_recurrence" (1/2/0/-1, default 1: the encoder recurrences as ONE split-f16 MFMA product per step for 16 chunks of a
  *                       direction per workgroup (raw layer 0 with its input projection in the lane, the other layers on inputs
  *                       pre-projected by an elementwise kernel / a split-f16 GEMM); 2 = the same with EIGHT chunks per workgroup,

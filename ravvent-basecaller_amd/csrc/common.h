@@ -53,7 +53,7 @@ void launch_lstm_rec_proj(const RecArgs& a, int rows_per_block, hipStream_t s);
 #define RV_MX_ROWS 16
 #define RV_UA_SLOT ((size_t)2 * RV_U * RV_G + 2 * RV_G)
 void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s, bool rows8 = false);   // rows8: eight chunks per workgroup (latency form)
-bool lstm_rec_mx_window_fits(int T);
+bool lstm_rec_mx_window_fits(int T, int F = 1);   // layer 0 with its input projection in the lane: do the input windows of a workgroup's chunks fit in LDS?
 hipError_t configure_mx_kernels();
 // xw [rows,2,512] = x [rows,F] . W_dir [F,512] + b_dir for a layer-0 encoder with F = 5 (or 1) input features, both directions
 // mask != null: also writes utils.input_mask of the rows, mask[(r / T) * mask_T + mask_t0 + r % T] = all(x[r, :] != pad)

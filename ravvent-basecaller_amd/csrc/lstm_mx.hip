@@ -42,15 +42,15 @@ __device__ __forceinline__ float ror8_add(float v) {           // v + (v of lane
 
 template <int F, int CH>
 __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
-  static_assert(F == 0 || F == 1, "pre-projected inputs, or one raw feature");
+  static_assert(F == 0 || F == 1 || F == 5, "pre-projected inputs, or layer 0 on its F input features (raw samples: 1; events: 5)");
   static_assert(CH == 16 || CH == 8, "sixteen chunks per workgroup, or eight with both parts of h in the product's columns");
   constexpr bool C8 = CH == 8;
   constexpr int NU = C8 ? 2 : 4;                                 // units per lane
   extern __shared__ __align__(16) char mxsm[];
   char* hb = mxsm;                                               // [2 buffers][2 parts][16 k-blocks][16 chunks][8 f16] = 16 KB  (CH = 8: [2][16 k-blocks][8 high | 8 low columns][8 f16])
   float* dss = reinterpret_cast<float*>(mxsm + 16384);           // [512] 2^-14 / s_r
-  float* wxs = dss + RV_G;                                       // F == 1: [512] input kernel row, [512] bias
-  float* xs = wxs + 2 * RV_G;                                    // F == 1: [CH][T] input windows
+  float* wxs = dss + RV_G;                                       // F > 0: [F][512] input kernel rows, [512] bias
+  float* xs = wxs + (F + 1) * RV_G;                              // F > 0: [CH][T][F] input windows
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
   const int nn = C8 ? n & 7 : n, hs = C8 ? n >> 3 : 0;           // chunk of the group; CH = 8: which half of the four units (and: high / low column)
@@ -73,16 +73,19 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
   {
     const float* dsg = reinterpret_cast<const float*>(a.Ua[dir] + (size_t)2 * RV_U * RV_G);
     dss[tid] = dsg[tid];
-    if (F == 1) {
-      wxs[tid] = a.W[dir][tid]; wxs[RV_G + tid] = a.bias[dir][tid];
-      const float* xg = a.ptab ? static_cast<const float*>(a.ptab[RV_PTAB_RAW]) : a.x;     // (graph replay: the caller's address of this call)
+    if (F > 0) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) wxs[f * RV_G + tid] = a.W[dir][f * RV_G + tid];
+      wxs[F * RV_G + tid] = a.bias[dir][tid];
+      const float* xg = a.ptab ? static_cast<const float*>(a.ptab[F == 1 ? RV_PTAB_RAW : RV_PTAB_EVENT]) : a.x;     // (graph replay: the caller's address of this call)
       for (int r = 0; r < CH; ++r) {
         const int b = min(b0 + r, a.B - 1);
-        const bool wm = a.mask && dir == 0 && b0 + r < a.B;     // utils.input_mask of the raw part (utils.py:26-32), once per chunk
+        const bool wm = a.mask && dir == 0 && b0 + r < a.B;     // utils.input_mask of this encoder's part (utils.py:26-32: all features != pad), once per chunk
         for (int i = tid; i < T; i += 512) {
-          const float v = xg[(size_t)b * T + i];
-          xs[r * T + i] = v;
-          if (wm) a.mask[(size_t)b * a.mask_T + a.mask_t0 + i] = v != a.pad ? 1 : 0;
+          bool real = true;
+#pragma unroll
+          for (int f = 0; f < F; ++f) { const float v = xg[((size_t)b * T + i) * F + f]; xs[(r * T + i) * F + f] = v; real = real && v != a.pad; }
+          if (wm) a.mask[(size_t)b * a.mask_T + a.mask_t0 + i] = real ? 1 : 0;
         }
       }
     }
@@ -195,11 +198,15 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
       const XV ds = ldx(&dss[g * RV_U + u0]);
       XV xin;
       if (F == 0) xin = xu[g];
-      else {
-        const float xv = xs[nn * T + t];
-        const XV wv = ldx(&wxs[g * RV_U + u0]), bv = ldx(&wxs[RV_G + g * RV_U + u0]);
+      else {                                                     // b + sum_f x_f w_f, features in order (the same additions as k_inproj_small: identical bits)
+        xin = ldx(&wxs[F * RV_G + g * RV_U + u0]);
 #pragma unroll
-        for (int i = 0; i < NU; ++i) xin.v[i] = fmaf(xv, wv.v[i], bv.v[i]);
+        for (int f = 0; f < F; ++f) {
+          const float xv = xs[(nn * T + t) * F + f];
+          const XV wv = ldx(&wxs[f * RV_G + g * RV_U + u0]);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) xin.v[i] = fmaf(xv, wv.v[i], xin.v[i]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) z[g][i] = fmaf(sacc[i], ds.v[i], xin.v[i]);
@@ -276,16 +283,17 @@ __global__ __launch_bounds__(256) void k_inproj_small(const float* __restrict__ 
   }
 }
 
-constexpr size_t mx_lds_bytes(int F, int T) { return 16384 + sizeof(float) * (3 * RV_G + (F == 1 ? (size_t)RV_MX_ROWS * T : 0)); }
+constexpr size_t mx_lds_bytes(int F, int T) { return 16384 + sizeof(float) * ((size_t)RV_G + (F > 0 ? (size_t)(F + 1) * RV_G + (size_t)RV_MX_ROWS * T * F : 2 * RV_G)); }
 
 }  // namespace
 
-bool lstm_rec_mx_window_fits(int T) { return mx_lds_bytes(1, T) <= 160 * 1024; }
+bool lstm_rec_mx_window_fits(int T, int F) { return mx_lds_bytes(F, T) <= 160 * 1024; }
 
 hipError_t configure_mx_kernels() {
   hipError_t first = hipSuccess;
   for (const void* f : {reinterpret_cast<const void*>(&k_lstm_rec_mx<0, 16>), reinterpret_cast<const void*>(&k_lstm_rec_mx<1, 16>),
-                        reinterpret_cast<const void*>(&k_lstm_rec_mx<0, 8>), reinterpret_cast<const void*>(&k_lstm_rec_mx<1, 8>)}) {
+                        reinterpret_cast<const void*>(&k_lstm_rec_mx<5, 16>), reinterpret_cast<const void*>(&k_lstm_rec_mx<0, 8>),
+                        reinterpret_cast<const void*>(&k_lstm_rec_mx<1, 8>), reinterpret_cast<const void*>(&k_lstm_rec_mx<5, 8>)}) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess && first == hipSuccess) first = e;
   }
@@ -296,11 +304,13 @@ void launch_lstm_rec_mx(const RecArgs& a, int F, hipStream_t s, bool rows8) {
   if (rows8) {                                                   // eight chunks per workgroup: the latency form (see the head of this file)
     dim3 grid((a.B + 7) / 8, 2);
     if (F == 1) hipLaunchKernelGGL((k_lstm_rec_mx<1, 8>), grid, dim3(512), mx_lds_bytes(1, a.T), s, a);
+    else if (F == 5) hipLaunchKernelGGL((k_lstm_rec_mx<5, 8>), grid, dim3(512), mx_lds_bytes(5, a.T), s, a);
     else hipLaunchKernelGGL((k_lstm_rec_mx<0, 8>), grid, dim3(512), mx_lds_bytes(0, a.T), s, a);
     return;
   }
   dim3 grid((a.B + RV_MX_ROWS - 1) / RV_MX_ROWS, 2);
   if (F == 1) hipLaunchKernelGGL((k_lstm_rec_mx<1, 16>), grid, dim3(512), mx_lds_bytes(1, a.T), s, a);
+  else if (F == 5) hipLaunchKernelGGL((k_lstm_rec_mx<5, 16>), grid, dim3(512), mx_lds_bytes(5, a.T), s, a);
   else hipLaunchKernelGGL((k_lstm_rec_mx<0, 16>), grid, dim3(512), mx_lds_bytes(0, a.T), s, a);
 }
 

@@ -88,6 +88,7 @@ struct RvContext {
   int opt_wide = 1;                         // matrix-pipe recurrence, 16 chunks per workgroup: 1 on (default: every call runs the same kernels whatever its slab
                                             // size, so results do not depend on how a read is cut into slabs / shards), 0 packed-FMA kernels, -1 per-call choice
   int lwide = 0;
+  int opt_lane_inproj = 1;                  // the event encoder's layer-0 input projection inside its matrix-pipe recurrence (0: k_inproj_small + pre-projected inputs)
   int lrows8 = 0;                           // this call's matrix-pipe recurrences take eight chunks per workgroup (the latency form of lstm_mx.hip)
   int opt_tail_wave = 1;                    // layer 0: cell update on a ninth wave, two row groups half a step apart
   int opt_fuse = 1;                         // layers >= 1: input projection inside the recurrence kernel (MFMA waves)
@@ -341,15 +342,17 @@ void run_encoder(RvContext* h, int e, const float* x, int F, int B, int T, int T
       // matrix-pipe recurrence.  Raw layer 0 folds its one-feature input projection in; every other layer reads pre-projected
       // inputs xw [B,T,2,512]: event layer 0 from a small elementwise kernel, layers >= 1 from the split-f16 GEMM (both directions
       // and their biases in one launch, A read once).
-      if (l == 0 && F == 1) {
+      if (l == 0 && (F == 1 || (F == 5 && h->opt_lane_inproj && lstm_rec_mx_window_fits(T, 5)))) {
+        // layer 0 takes x . W + b in the lane, from LDS windows of its chunks' inputs: no projection launch, no xw round trip (round 4: the
+        // event encoder's five features too -- the same fused multiply-adds in the same order as k_inproj_small: identical bits)
         a.x = x;
         for (int dr = 0; dr < 2; ++dr) { a.W[dr] = h->enc[e][0][dr].W; a.bias[dr] = h->enc[e][0][dr].b; }
         a.mask = h->mask; a.mask_T = Tm; a.mask_t0 = t_off; a.pad = h->cfg.padding_value;   // the layer-0 kernels leave the input mask too
         a.ptab = ptab;
         a.dbg_ts = (e == 0 && h->rec_ts_layer == 0) ? h->rec_ts : nullptr;     // (RV_REC_STAMPS=1: phase cycle sums of workgroup (0, 0))
-        Scope sc(h, "lstm_rec_raw_l0", s);
-        launch_lstm_rec_mx(a, 1, s, h->lrows8 != 0);
-        a.dbg_ts = nullptr;
+        Scope sc(h, F == 1 ? "lstm_rec_raw_l0" : "lstm_rec_event_l0", s);
+        launch_lstm_rec_mx(a, F, s, h->lrows8 != 0);
+        a.dbg_ts = nullptr; a.ptab = nullptr; a.mask = nullptr;
         continue;
       }
       if (l == 0) {
@@ -922,7 +925,7 @@ int create_child(RvContext* p, RvContext** out) {
 // options and weight-derived scalars of the parent, as of now
 void sync_child(RvContext* k, const RvContext* p) {
   k->loaded = p->loaded; k->mx_kscale = p->mx_kscale; k->mx_uscale = p->mx_uscale;
-  k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_persist = p->opt_persist;
+  k->opt_split = p->opt_split; k->opt_att_nt = p->opt_att_nt; k->opt_side_ev = p->opt_side_ev; k->opt_lane_inproj = p->opt_lane_inproj; k->opt_persist = p->opt_persist;
   k->opt_flash = p->opt_flash; k->opt_split_proj = p->opt_split_proj; k->opt_mx_att = p->opt_mx_att; k->opt_mx_cell = p->opt_mx_cell; k->mx_cdescale = p->mx_cdescale; k->mx_ldescale = p->mx_ldescale; k->opt_tail_wave = p->opt_tail_wave;
   k->mx_qdescale = p->mx_qdescale; k->mx_c1descale = p->mx_c1descale;
   k->opt_fuse = p->opt_fuse; k->opt_wide = p->opt_wide; k->opt_graph = p->opt_graph; k->opt_profile = p->opt_profile;
@@ -1462,6 +1465,7 @@ int rv_set_option(rv_handle h, const char* key, int32_t value) {
   else if (!strcmp(key, "flash_attend")) h->opt_flash = value != 0;
   else if (!strcmp(key, "persistent_decode")) h->opt_persist = value != 0;
   else if (!strcmp(key, "concurrent_encoders")) h->opt_side_ev = value != 0;
+  else if (!strcmp(key, "lane_projection")) h->opt_lane_inproj = value != 0;
   else if (!strcmp(key, "fused_projection")) h->opt_fuse = value != 0;
   else if (!strcmp(key, "tail_wave")) h->opt_tail_wave = value != 0;
   else if (!strcmp(key, "wide_recurrence")) h->opt_wide = value < 0 ? -1 : (value == 2 ? 2 : (value != 0));

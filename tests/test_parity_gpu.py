@@ -468,6 +468,30 @@ def test_matrix_pipe_recurrence_matches_fma_path_and_oracle(rv, oracle, mode, B,
     bc.close()
 
 
+@pytest.mark.parametrize("mode,B,Tr,Te,wide", [("joint", 37, 60, 17, 1), ("event", 130, 1, 45, 1), ("joint", 21, 40, 30, 2), ("event", 9, 1, 1, 2)])
+def test_event_projection_in_the_lane_is_bit_identical(rv, mode, B, Tr, Te, wide):
+    """Option lane_projection: the event encoder's layer 0 with its five-feature input projection inside the matrix-pipe recurrence (inputs
+    staged in LDS, the same fused multiply-adds in the same order) against k_inproj_small + pre-projected inputs: byte-identical encoder
+    output, input mask, tokens and scores; padded events (the mask's all-features test), slabs that are not multiples of 8 / 16 chunks, both
+    workgroup sizes of the recurrence; and the projection launch really is gone."""
+    bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, encoder_depth=2, max_batch=B, max_raw_len=max(Tr, 1), max_event_len=max(Te, 1))
+    bc.init_random_weights(seed=5, gain=2.0)
+    raw, ev, _ = rv.synthetic.make_slab(B, Tr, Te, seed=B, max_raw_pad=min(15, Tr - 1), max_event_pad=min(10, Te - 1))
+    x = _inputs(rv, mode, raw, ev)
+    bc.set_option("wide_recurrence", wide)
+    bc.set_option("profile", 1)
+    got = {}
+    for lane in (1, 0):
+        bc.set_option("lane_projection", lane)
+        bc.reset_profile()
+        tok, sc = bc.beam_search_prediction(x, 5, 10)
+        assert ("inproj_event_l0" in bc.profile()) == (lane == 0)
+        got[lane] = (tok.numpy().copy(), sc.numpy().copy(), bc.get_tensor("enc_output").copy(), bc.get_tensor("mask").copy())
+    for a, b in zip(got[1], got[0]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    bc.close()
+
+
 @pytest.mark.parametrize("scale_cols", [False, True])
 def test_split_projection_is_as_close_to_fp64_as_the_f32_mfma(rv, oracle, scale_cols):
     """rv_set_option("split_projection"): the input projection of encoder layers >= 1 on 16-bit MFMAs with split operands
@@ -509,7 +533,7 @@ def test_every_documented_option_is_accepted(rv):
     keys = set(re.findall(r'"([a-z_]+)"\s*\(', doc))
     assert {"debug_taps", "use_graph", "decode_split", "attend_threads", "flash_attend", "concurrent_encoders",
             "fused_projection", "persistent_decode", "persist_taps", "tail_wave", "split_projection", "matrix_attention", "matrix_cell", "profile",
-            "wide_recurrence", "async_depth", "slab_graph"} <= keys
+            "wide_recurrence", "async_depth", "slab_graph", "lane_projection"} <= keys
     bc, _ = _mk(rv)
     for k in sorted(keys):
         bc.set_option(k, 1 if k != "attend_threads" else 256)

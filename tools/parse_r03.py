@@ -8,7 +8,7 @@ CLOCK_GHZ = 2.4          # MI355X peak engine clock: utilisation = MFMA-busy cyc
 def slab_names(form):
     """Kernel launches of one synchronous C3 slab, in launch order -> bench.py's names."""
     if form == "mx":
-        seq = [("k_inproj_small", "inproj_event_l0"), ("k_lstm_rec_mx<0,", "lstm_rec_event_l0"),
+        seq = [("k_lstm_rec_mx<5,", "lstm_rec_event_l0"),
                ("k_gemm_ws", "gemm_inproj_event"), ("k_lstm_rec_mx<0,", "lstm_rec_event_l1p"), ("k_lstm_rec_mx<1,", "lstm_rec_raw_l0"),
                ("k_gemm_ws", "gemm_inproj_raw"), ("k_lstm_rec_mx<0,", "lstm_rec_raw_l1p"), ("k_gemm_mem_split3", "gemm_memory"),
                ("k_dec_persist", "dec_persist"), ("k_dec_finalize", "dec_finalize")]
