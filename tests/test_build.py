@@ -31,7 +31,7 @@ LIMITS = {
     r"k_gemm_mem_split3": 0,                     # attention-memory projection on split-f16 MFMAs (compute waves + loader waves)
     r"k_lstm_recILi2ELi1EE": 0, r"k_lstm_recILi2ELi5EE": 0,
     r"k_lstm_rec_twILi2ELi1EE": 0, r"k_lstm_rec_twILi2ELi5EE": 0,   # C3 layer 0 (tail-wave variant)
-    r"k_lstm_rec_mxILi[01]ELi(16|8)EE": 0,       # matrix-pipe recurrence (16 / 8 chunks per workgroup): U^T resident as A fragments (128 VGPRs)
+    r"k_lstm_rec_mxILi[015]ELi(16|8)EE": 0,      # matrix-pipe recurrence (inputs pre-projected / raw / events; 16 / 8 chunks per workgroup): U^T resident as A fragments (128 VGPRs)
 }
 
 
