@@ -36,12 +36,182 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define RV_MX_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+// The sixteen-chunk form with pre-projected inputs or one raw feature, as round 3 wrote it: the default path's kernels.  (The generic body
+// below -- eight chunks per workgroup, five input features -- compiles to the same instruction counts for these two cases and ran 1-3 % slower
+// on the same box, same inputs: 0.3945 -> 0.3990 ms for raw layer 0, 0.4035 -> 0.4155 for layer 1; the scheduling differs, not the work.)
+template <int F>
+__device__ __forceinline__ void rec_mx16_body(const RecArgs& a) {
+  static_assert(F == 0 || F == 1, "pre-projected inputs, or one raw feature");
+  extern __shared__ __align__(16) char mxsm[];
+  char* hb = mxsm;                                               // [2 buffers][2 parts][16 k-blocks][16 chunks][8 f16] = 16 KB
+  float* dss = reinterpret_cast<float*>(mxsm + 16384);           // [512] 2^-14 / s_r
+  float* wxs = dss + RV_G;                                       // F == 1: [512] input kernel row, [512] bias
+  float* xs = wxs + 2 * RV_G;                                    // F == 1: [16][T] input windows
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int dir = blockIdx.y, b0 = blockIdx.x * RV_MX_ROWS, T = a.T;
+  const int bc = min(b0 + n, a.B - 1);                           // rows beyond the slab compute on a copy of its last chunk, never stored
+  const bool live = b0 + n < a.B;
+  const int u0 = 16 * w + 4 * q;                                 // this lane's 4 units
+
+  // ---- U^T -> registers (A fragments), once
+  float4 ua[4][4][2];
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.Ua[dir]) + (size_t)w * (4 * 4 * 2 * 64) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ua[g][ks][p] = src[((g * 4 + ks) * 2 + p) * 64];
+  }
+  {
+    const float* dsg = reinterpret_cast<const float*>(a.Ua[dir] + (size_t)2 * RV_U * RV_G);
+    dss[tid] = dsg[tid];
+    if (F == 1) {
+      wxs[tid] = a.W[dir][tid]; wxs[RV_G + tid] = a.bias[dir][tid];
+      const float* xg = a.ptab ? static_cast<const float*>(a.ptab[RV_PTAB_RAW]) : a.x;     // (graph replay: the caller's address of this call)
+      for (int r = 0; r < RV_MX_ROWS; ++r) {
+        const int b = min(b0 + r, a.B - 1);
+        const bool wm = a.mask && dir == 0 && b0 + r < a.B;     // utils.input_mask of the raw part (utils.py:26-32), once per chunk
+        for (int i = tid; i < T; i += 512) {
+          const float v = xg[(size_t)b * T + i];
+          xs[r * T + i] = v;
+          if (wm) a.mask[(size_t)b * a.mask_T + a.mask_t0 + i] = v != a.pad ? 1 : 0;
+        }
+      }
+    }
+  }
+  // ---- initial state: c in registers, h as the first B image
+  float c[4];
+  {
+    float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), c0 = h0;
+    if (a.h0[dir]) { h0 = *reinterpret_cast<const float4*>(a.h0[dir] + (size_t)bc * RV_U + u0); c0 = *reinterpret_cast<const float4*>(a.c0[dir] + (size_t)bc * RV_U + u0); }
+    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+    const float hv[4] = {h0.x, h0.y, h0.z, h0.w};
+    h4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float sv = hv[i] * 16384.f; hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]); }
+    char* dst = hb + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
+    *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
+  }
+  // pre-projected inputs: the loads of step s + 2 are issued in step s (one step, ~1.3 us, is less than an HBM round trip under
+  // load) into a ring of three register sets; the step loop is unrolled by three so that no set is ever COPIED -- a register
+  // move from a load's destination waits for the load, which is what made a "prefetch" into a staging set synchronous
+  float4 xc[4], xn[4], xnn[4];
+  const float* xrow = F == 0 ? a.x + ((size_t)bc * T * 2 + dir) * RV_G + u0 : nullptr;    // + t * 1024 + g * 128
+  if (F == 0) {
+    const int t0 = dir ? T - 1 : 0, t1 = dir ? max(T - 2, 0) : min(1, T - 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xc[g] = *reinterpret_cast<const float4*>(xrow + (size_t)t0 * (2 * RV_G) + g * RV_U);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xn[g] = *reinterpret_cast<const float4*>(xrow + (size_t)t1 * (2 * RV_G) + g * RV_U);
+  }
+  __syncthreads();
+
+  float hl[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  // diagnostic (RV_REC_STAMPS, tools/rec_stamps.py): cycle sums of workgroup (0, 0), wave 0 over all steps: [0] top of step -> gate sums in
+  // registers, [1] -> cell update done, [2] -> LDS image and output store issued, [3] -> behind the barrier
+#ifdef RV_MX_STAMPS      // diagnostic builds only (make mxvar V=1 MXFLAGS=-DRV_MX_STAMPS; RAVVENT_HIP_LIB=...libravvent_hip_m1.so): four scalar branches per step otherwise
+  const bool stamp = a.dbg_ts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#else
+  constexpr bool stamp = false;
+#endif
+  long long st_sum[4] = {0, 0, 0, 0};
+  auto step = [&](int s, const float4 (&xu)[4], float4 (&xl)[4]) {
+    const int t = dir ? T - 1 - s : s;
+    long long st0 = 0;
+    if (stamp) st0 = __builtin_readcyclecounter();
+    if (F == 0) {                                                // the inputs of step s + 2: in flight across two barriers
+      const int tn = dir ? max(t - 2, 0) : min(t + 2, T - 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xl[g] = *reinterpret_cast<const float4*>(xrow + (size_t)tn * (2 * RV_G) + g * RV_U);
+    }
+    f4v acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+    const char* hp = hb + cur * 8192 + (q * 16 + n) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const h8 bh = *reinterpret_cast<const h8*>(hp + ks * 1024), bl = *reinterpret_cast<const h8*>(hp + 4096 + ks * 1024);
+      // the four gates in turns for each part product: an MFMA accumulates onto a result that is four instructions old, not onto the one
+      // issued just before it (per accumulator the order of the additions is unchanged: identical results)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][0]), bl, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][1]), bh, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ua[g][ks][0]), bh, acc[g], 0, 0, 0);
+    }
+    // ---- gate pre-activations of this lane's 4 units, cell update (i, f, c~, o)
+    float z[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 ds = *reinterpret_cast<const float4*>(&dss[g * RV_U + u0]);
+      float4 xin;
+      if (F == 0) xin = xu[g];
+      else {
+        const float xv = xs[n * T + t];
+        const float4 wv = *reinterpret_cast<const float4*>(&wxs[g * RV_U + u0]), bv = *reinterpret_cast<const float4*>(&wxs[RV_G + g * RV_U + u0]);
+        xin = make_float4(fmaf(xv, wv.x, bv.x), fmaf(xv, wv.y, bv.y), fmaf(xv, wv.z, bv.z), fmaf(xv, wv.w, bv.w));
+      }
+      z[g][0] = fmaf(acc[g][0], ds.x, xin.x); z[g][1] = fmaf(acc[g][1], ds.y, xin.y);
+      z[g][2] = fmaf(acc[g][2], ds.z, xin.z); z[g][3] = fmaf(acc[g][3], ds.w, xin.w);
+    }
+    if (stamp) { asm volatile("" :: "v"(z[0][0]), "v"(z[3][3])); const long long tn = __builtin_readcyclecounter(); st_sum[0] += tn - st0; st0 = tn; }
+    h4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // (Round 4 tried this update on 7 transcendentals instead of 10 -- c' and h' each as ONE reciprocal of a product of (1 + 2^x) terms --
+      //  parity-green and no faster: 0.394 / 0.424 ms per C3 layer either way.  The step is bound by the SIMD's issue with both of its waves
+      //  in the same phase -- tools/mx_stamps.py: 1.24 k cycles of MFMA phase + 1.0 k of cell update + 0.26 k + 0.7 k at the barrier -- and a
+      //  two-group form that interleaves one group's MFMAs with the other's cell update inside every wave did not overlap them either
+      //  (DESIGN.md section 7).)
+      const float cc = fmaf(rv_sigmoid(z[1][i]), c[i], rv_sigmoid(z[0][i]) * rv_tanh(z[2][i]));
+      const float hh = rv_sigmoid(z[3][i]) * rv_tanh(cc);
+      c[i] = cc; hl[i] = hh;
+      const float sv = hh * 16384.f;
+      hi[i] = (_Float16)sv; lo[i] = (_Float16)(sv - (float)hi[i]);
+    }
+    if (stamp) { asm volatile("" :: "v"(hl[0]), "v"(hl[3])); const long long tn = __builtin_readcyclecounter(); st_sum[1] += tn - st0; st0 = tn; }
+    {
+      char* dst = hb + (cur ^ 1) * 8192 + ((2 * w + (q >> 1)) * 16 + n) * 16 + (q & 1) * 8;
+      *reinterpret_cast<h4*>(dst) = hi; *reinterpret_cast<h4*>(dst + 4096) = lo;
+    }
+    if (live)
+      *reinterpret_cast<float4*>(a.out + ((size_t)(b0 + n) * a.out_T + a.out_t0 + t) * RV_E + dir * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
+    cur ^= 1;
+    if (stamp) { const long long tn = __builtin_readcyclecounter(); st_sum[2] += tn - st0; st0 = tn; }
+    RV_MX_BARRIER();
+    if (stamp) { const long long tn = __builtin_readcyclecounter(); st_sum[3] += tn - st0; }
+  };
+  // whole triples in the loop, the one or two steps that are left after it: a conditional step INSIDE the loop makes the compiler merge
+  // two histories of pending loads / stores at the loop header, and it then drains the vector-memory counter there (`s_waitcnt vmcnt(0)`
+  // once per three steps: the wave waited for the previous step's output store and for inputs it had requested one step earlier)
+  int s = 0;
+  for (; s + 2 < T; s += 3) {
+    step(s, xc, xnn);
+    step(s + 1, xn, xc);
+    step(s + 2, xnn, xn);
+  }
+  if (s < T) {
+    step(s, xc, xnn);
+    if (s + 1 < T) step(s + 1, xn, xc);
+  }
+  if (stamp) { for (int i = 0; i < 4; ++i) a.dbg_ts[i] = st_sum[i]; a.dbg_ts[4] = T; }
+  if (live) {
+    *reinterpret_cast<float4*>(a.hT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(hl[0], hl[1], hl[2], hl[3]);
+    *reinterpret_cast<float4*>(a.cT[dir] + (size_t)(b0 + n) * RV_U + u0) = make_float4(c[0], c[1], c[2], c[3]);
+  }
+}
+
 __device__ __forceinline__ float ror8_add(float v) {           // v + (v of lane n ^ 8 of this 16-lane row)
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
 }
 
 template <int F, int CH>
-__global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
+__device__ __forceinline__ void rec_mx_body(const RecArgs& a) {
   static_assert(F == 0 || F == 1 || F == 5, "pre-projected inputs, or layer 0 on its F input features (raw samples: 1; events: 5)");
   static_assert(CH == 16 || CH == 8, "sixteen chunks per workgroup, or eight with both parts of h in the product's columns");
   constexpr bool C8 = CH == 8;
@@ -253,6 +423,12 @@ __global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) { a.hT[dir][(size_t)(b0 + nn) * RV_U + u0 + i] = hl[i]; a.cT[dir][(size_t)(b0 + nn) * RV_U + u0 + i] = c[i]; }
   }
+}
+
+template <int F, int CH>
+__global__ __launch_bounds__(512) void k_lstm_rec_mx(RecArgs a) {
+  if constexpr (CH == 16 && F != 5) rec_mx16_body<F>(a);
+  else rec_mx_body<F, CH>(a);
 }
 
 // x . W + b for a layer-0 encoder with a handful of input features (the event encoder: F = 5), both directions:
