@@ -5,7 +5,7 @@
   (dist.sharded_beam_search_many's form) -- byte-identical to the synchronous call per slab, twenty DISTINCT slabs, and one slab
   against the C port with every differing row settled by the fp64 oracle;
 * a synchronous call while the handle's own context holds an uncollected ticket (ADVICE r03);
-* the random sweep of tools/stress_paths.py (five forms of the path against each other, asynchronous calls, greedy) with every token
+* the random sweep of tools/stress_paths.py (six forms of the path against each other, asynchronous calls, greedy) with every token
   OR score difference routed through the fp64 re-decode of test_parity_gpu._explain_mismatches -- incl. the case of
   gpurun_out/r3b_stress.log (seed 123, case 88) that differed by 9.2e-4 in a score and was printed, not counted;
 * adversarial recurrent kernels for the matrix-pipe recurrence's `Ua` image (per-gate-column power-of-two factors, lstm_mx.hip).
@@ -120,12 +120,12 @@ def _explain_greedy(oracle, w, cfg, mode, raw, ev, L, a, b, tag):
     return int(bad.size)
 
 
-FORMS = {"pf": (1, 1, 1, 1), "sf": (0, 1, 1, 1), "pu": (1, 0, 0, 1), "fm": (1, 1, 0, 1), "fc": (1, 1, 1, 0)}
+FORMS = {"pf": (1, 1, 1, 1), "sf": (0, 1, 1, 1), "pu": (1, 0, 0, 1), "fm": (1, 1, 0, 1), "fc": (1, 1, 1, 0), "p8": (1, 1, 2, 1)}
 
 
 def _sweep_case(rv, oracle, mode, enc_d, dec_d, B, T_r, T_e, W, L, att, wseed, end_bias, xseed, tag):
     """One case of the sweep: the default path (pf), the per-step decode kernels (sf), the packed-FMA recurrences with an unfused (pu) /
-    fused (fm) projection and the decoder cell's product on packed FMAs (fc) on the same slab; every pair (pf, other) must agree row by
+    fused (fm) projection, the decoder cell's product on packed FMAs (fc) and the eight-chunk matrix-pipe recurrences (p8) on the same slab; every pair (pf, other) must agree row by
     row in tokens AND scores, or the fp64 oracle must explain the row for BOTH forms (test_parity_gpu._explain_mismatches)."""
     from test_parity_gpu import _explain_mismatches
     bc = rv.Basecaller(128, 128, 128, rv.data_loader.nuc_tk, mode, 0.0, encoder_depth=enc_d, decoder_depth=dec_d, max_batch=B,
@@ -148,7 +148,7 @@ def _sweep_case(rv, oracle, mode, enc_d, dec_d, B, T_r, T_e, W, L, att, wseed, e
         g, lg = bc.greedy_search_prediction(x, L)
         out[key] = (t.numpy().copy(), s.numpy().copy(), g.numpy().copy(), lg.numpy().copy())
     n_rows = n_greedy = 0
-    for other in ("sf", "pu", "fm", "fc"):
+    for other in ("sf", "pu", "fm", "fc", "p8"):
         a, b = out["pf"], out[other]
         assert a[0].shape == b[0].shape, f"{tag} vs {other}: beam shapes {a[0].shape} / {b[0].shape}"
         if a[0].size:
@@ -190,7 +190,7 @@ def test_stress_sweep_every_difference_explained(rv, oracle, seed):
         r, g = _sweep_case(rv, oracle, mode, enc_d, dec_d, B, T_r, T_e, W, L, att, wseed, end_bias, case,
                            f"seed {seed} case {case} {(mode, att, enc_d, dec_d, B, T_r, T_e, W, L)}")
         tot[0] += r; tot[1] += g
-    print(f"seed {seed}: 24 cases x 5 forms; {tot[0]} beam rows and {tot[1]} greedy rows differed between forms, all explained by the fp64 oracle")
+    print(f"seed {seed}: 24 cases x 6 forms; {tot[0]} beam rows and {tot[1]} greedy rows differed between forms, all explained by the fp64 oracle")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ for case in range(n):
     raw, ev, _ = rv.synthetic.make_slab(B, T_r, T_e, seed=case, max_raw_pad=min(15, T_r - 1), max_event_pad=min(10, T_e - 1))
     x = (raw, ev) if mode == "joint" else (raw if mode == "raw" else ev)
     out = {}
-    for key, (persist, fuse, wide, mcell) in {"pf": (1, 1, 1, 1), "sf": (0, 1, 1, 1), "pu": (1, 0, 0, 1), "fm": (1, 1, 0, 1), "fc": (1, 1, 1, 0)}.items():
+    for key, (persist, fuse, wide, mcell) in {"pf": (1, 1, 1, 1), "sf": (0, 1, 1, 1), "pu": (1, 0, 0, 1), "fm": (1, 1, 0, 1), "fc": (1, 1, 1, 0), "p8": (1, 1, 2, 1)}.items():
         bc.set_option("persistent_decode", persist); bc.set_option("fused_projection", fuse); bc.set_option("wide_recurrence", wide)
         bc.set_option("matrix_cell", mcell)          # fc: the decoder cell's product on packed FMAs instead of the matrix pipe
         t, s = bc.beam_search_prediction(x, W, L)
@@ -37,7 +37,7 @@ for case in range(n):
         g, lg = bc.greedy_search_prediction(x, L)
         out[key] = (t.numpy().copy(), s.numpy().copy(), g.numpy().copy(), lg.numpy().copy())
     ok = True
-    for other in ("sf", "pu", "fm", "fc"):
+    for other in ("sf", "pu", "fm", "fc", "p8"):
         a, b = out["pf"], out[other]
         same = a[0].shape == b[0].shape and (a[0] == b[0]).all(axis=1).mean() >= 0.98 if a[0].size else a[0].shape == b[0].shape
         rows = (a[0] == b[0]).all(axis=1) if a[0].size and a[0].shape == b[0].shape else np.zeros(0, bool)
