@@ -186,7 +186,7 @@ int rv_greedy_search_dev(rv_handle h, const float* d_raw, const float* d_event, 
  *                       option is set -- when the value exceeds GPU_MAX_HW_QUEUES as found in the environment, see "Hardware queues" above),
  *          "slab_graph" (0/1, default 0: a call on the default path -- matrix-pipe recurrences, persistent decode, no profiling, no taps --
  *                       replays as ONE hipGraphLaunch per slab (captured per slab context and call shape; the caller's input / output
- *                       addresses reach the kernels through a table in mapped pinned memory) instead of ten kernel launches: half the
+ *                       addresses reach the kernels through a table in mapped pinned memory) instead of nine kernel launches (ten with "lane_projection" 0): half the
  *                       host time per call (24 us against 46), but the replayed slabs stream 1.5-3 % slower on ROCm 7.2, so it is off
  *                       unless a caller's host thread is the bottleneck; results are identical),
  *          "persistent_decode" (0/1, default 1: Luong beam search (beam <= 8; <= 5 with two decoder cells) and greedy search, no
